@@ -1,0 +1,94 @@
+"""Live check of the CPU oracle against the reference itself: the reference Python
+environment driving the compiled reference AssemblyEnv.cpp (oracle/_ref).  Runs
+only where /root/reference is present (the build container); skipped elsewhere."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import ref_env
+
+pytestmark = pytest.mark.skipif(not ref_env.available(), reason="reference tree / oracle/_ref not present")
+
+
+@pytest.mark.parametrize("seed,n_a,steps,kw", [
+    (226, 30, 200, {}),
+    (31, 30, 120, dict(is_boundary=False)),
+    (32, 30, 60, dict(is_con_self_state=False)),
+    (33, 10, 100, {}),
+    (34, 64, 60, {}),
+    (35, 30, 150, dict(warm=100)),
+    (36, 256, 4, {}),
+])
+def test_free_running_bit_exact(seed, n_a, steps, kw):
+    warm = kw.pop("warm", 0)
+    np.random.seed(seed)
+    env = ref_env.make_ref_env(n_a=n_a, agent_strategy="rule" if warm else "input", **kw)
+    e = env.env
+    obs = env.reset()
+    for _ in range(warm):
+        env.step(np.zeros((2, n_a), np.float32))
+    e.agent_strategy = "input"
+    cfg = ol.make_cfg(n_a=n_a, r_avoid=e.r_avoid, is_boundary=kw.get("is_boundary", True),
+                      is_con_self_state=kw.get("is_con_self_state", True))
+    p = e.p.copy(); dp = e.dp.copy(); grid = np.ascontiguousarray(e.grid_center)
+    obs2, _, nbr, inf, sen, occ = ol.env_observe(cfg, p, dp, grid, e.l_cell)
+    assert np.array_equal(obs2, e.obs) and np.array_equal(nbr, e.neighbor_index)
+    for t in range(steps):
+        a = np.random.uniform(-1, 1, (2, n_a)).astype(np.float32)
+        obs, rew, done, info, prior = env.step(a)
+        o, r, ap, inf, sen, occ, co = ol.env_step(cfg, p, dp, a, grid, e.l_cell, nbr)
+        for name, got, want in [("obs", o, obs), ("rew", r, rew), ("prior", ap, prior), ("p", p, e.p), ("dp", dp, e.dp),
+                                ("nbr", nbr, e.neighbor_index), ("in_flags", inf, e.in_flags),
+                                ("sensed", sen, e.sensed_index), ("occupied", occ, e.occupied_index),
+                                ("collide", co, e.is_collide_b2b)]:
+            assert np.array_equal(got, want), f"{name} differs at step {t}"
+
+
+def test_five_functions_direct():
+    """oracle_* vs the compiled reference symbols on the same inputs."""
+    ref = ol.reference_fns(); orc = ol.oracle_fns()
+    from marl_amd.shapes import load_shapes
+    l_cells, grids = load_shapes()
+    rng = np.random.default_rng(0)
+    bpos = np.array([-2.4, 2.4, 2.4, -2.4])
+    for trial in range(6):
+        s = trial % 7; grid = np.ascontiguousarray(grids[s].T + rng.uniform(-1, 1, (2, 1)))
+        n_a = [5, 30, 30, 47, 30, 100][trial]
+        p = np.ascontiguousarray(grid[:, rng.choice(grid.shape[1], n_a)] + rng.normal(0, 0.08, (2, n_a)))
+        dp = rng.uniform(-0.5, 0.5, (2, n_a)); heading = rng.uniform(-1, 1, (2, n_a))
+        for cond in [(False, True, True, False), (True, True, False, False), (False, False, True, False)]:
+            a = ref.get_observation(p, dp, heading, bpos, grid, 0.4, 0.26, l_cells[s], cond=cond)
+            b = orc.get_observation(p, dp, heading, bpos, grid, 0.4, 0.26, l_cells[s], cond=cond)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        obs, nbr, inf, sen, occ = a
+        for periodic in (False, True):
+            cond = (periodic, True, True, True, True)
+            assert np.array_equal(ref.get_reward(p, dp, heading, dp, bpos, grid, nbr, inf, sen, occ, 0.4, 0.26, l_cells[s], cond),
+                                  orc.get_reward(p, dp, heading, dp, bpos, grid, nbr, inf, sen, occ, 0.4, 0.26, l_cells[s], cond))
+            dc, de, co = ol.get_dist_b2b(p, periodic=periodic)
+            assert np.array_equal(ref.sf_b2b_all(p, de, co, bpos, dc, 30.0, periodic), orc.sf_b2b_all(p, de, co, bpos, dc, 30.0, periodic))
+        size = np.full(n_a, 0.035)
+        pw = p * 1.6
+        for x, y in zip(ref.get_dist_b2w(pw, size, bpos), orc.get_dist_b2w(pw, size, bpos)):
+            assert np.array_equal(x, y)
+        assert np.array_equal(ref.prior(p, dp, grid, nbr, 0.4, 0.26, l_cells[s]), orc.prior(p, dp, grid, nbr, 0.4, 0.26, l_cells[s]))
+
+
+def test_run_envs_driver_matches_reference_binding():
+    """The OpenMP CPU-baseline driver gives the same reward checksum whether it calls
+    the restatement or the compiled reference library."""
+    from marl_amd.shapes import load_shapes
+    l_cells, grids = load_shapes()
+    E, T, n_a = 8, 30, 30
+    sid, p, dp, grid, n_g, l_cell = ol.batch_reset(226, 0, 0, E, n_a, grids, l_cells, 544)
+    act = np.random.default_rng(1).uniform(-1, 1, (T, E, 2, n_a)).astype(np.float32)
+    cfg = ol.make_cfg(n_a=n_a, r_avoid=0.26)
+    ol.bind(None)
+    p1, d1 = p.copy(), dp.copy(); s1 = ol.run_envs(cfg, T, 2, p1, d1, act, grid, n_g, l_cell)
+    ol.bind(ol.REF_SO)
+    try:
+        p2, d2 = p.copy(), dp.copy(); s2 = ol.run_envs(cfg, T, 1, p2, d2, act, grid, n_g, l_cell)
+    finally:
+        ol.bind(None)
+    assert s1 == s2 and np.array_equal(p1, p2) and np.array_equal(d1, d2)
