@@ -1,0 +1,191 @@
+/*
+ * libAssemblyEnv.so — MI355X (gfx950) implementation of the assembly-environment
+ * step path.  C ABI only: plain pointers, sizes and scalars.
+ *
+ * Reference files cited below (relative to the reference repository root):
+ *   HDR  = cus_gym/gym/envs/customized_envs/envs_cplus/src/AssemblyEnv.h
+ *   CPP  = cus_gym/gym/envs/customized_envs/envs_cplus/src/AssemblyEnv.cpp
+ *   ENV  = cus_gym/gym/envs/customized_envs/assembly.py
+ *   CLIB = cus_gym/gym/envs/customized_envs/envs_cplus/c_lib.py
+ *
+ * Two groups of entry points:
+ *
+ *  (A) The five symbols the reference environment binds through ctypes
+ *      (CLIB:11-45 loads build/libAssemblyEnv.so; ENV:229, 352, 490, 455, 608 call
+ *      them).  Same names, same argument lists, same row-major layouts, HOST
+ *      pointers to double / int32 / bool, outputs overwritten in place, `void`
+ *      return.  Each call copies its inputs to the GPU, runs the double-precision
+ *      instantiation of the HIP kernels for one environment and copies the outputs
+ *      back.  There is no CPU fallback: without a usable HIP device the call
+ *      prints the HIP error and aborts.
+ *
+ *  (B) The batched interface: E independent environments per launch, DEVICE
+ *      pointers, fp32 state, a HIP stream argument, `int` status return
+ *      (0 = ok; asm_last_error() gives the message).  No reference counterpart —
+ *      the reference steps one environment per call (ENV:482-661); these are
+ *      that step, the observation-only half used by reset (ENV:216) and the
+ *      domain-randomised reset (ENV:151-218) over a batch.
+ *      Nothing here allocates, frees or synchronises: every buffer is the
+ *      caller's, work is enqueued on `stream`.
+ */
+#ifndef MARL_AMD_ENV_H
+#define MARL_AMD_ENV_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASM_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ (A) -- */
+
+/* replaces HDR:13-34 / CPP:23-356 (called at ENV:229-250) */
+void _get_observation(double *p_input, double *dp_input, double *heading_input, double *obs_input,
+                      double *boundary_pos_input, double *grid_center_input,
+                      int *neighbor_index_input, int *in_flags_input, int *sensed_index_input,
+                      int *occupied_index_input, double d_sen, double r_avoid, double l_cell,
+                      double Vel_max, int topo_nei_max, int num_obs_grid_max,
+                      int num_occupied_grid_max, int n_a, int n_g, int obs_dim_agent, int dim,
+                      bool *condition);
+
+/* replaces HDR:35-58 / CPP:359-631 (called at ENV:352-375) */
+void _get_reward(double *p_input, double *dp_input, double *heading_input, double *act_input,
+                 double *reward_input, double *boundary_pos_input, double *grid_center_input,
+                 int *neighbor_index_input, int *in_flags_input, int *sensed_index_input,
+                 int *occupied_index_input, double d_sen, double r_avoid, double l_cell,
+                 int topo_nei_max, int num_obs_grid_max, int num_occupied_grid_max, int n_a, int n_g,
+                 int dim, bool *condition, bool *is_collide_b2b_input, bool *is_collide_b2w_input,
+                 double *coefficients);
+
+/* replaces HDR:64-73 / CPP:740-820 (called at ENV:490-499) */
+void _sf_b2b_all(double *p_input, double *sf_b2b_input, double *d_b2b_edge_input,
+                 bool *is_collide_b2b_input, double *boundary_pos_input, double *d_b2b_center_input,
+                 int n_a, int dim, double k_ball, bool is_periodic);
+
+/* replaces HDR:75-81 / CPP:822-860 (called at ENV:455-461) */
+void _get_dist_b2w(double *p_input, double *r_input, double *d_b2w_input, bool *isCollision_input,
+                   int dim, int n_a, double *boundary_pos);
+
+/* replaces HDR:98-109 / CPP:1066-1123 (called at ENV:608-619) */
+void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_input,
+                          double *grid_center_input, int *neighbor_index_input, double d_sen,
+                          double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim);
+
+/* ------------------------------------------------------------------ (B) -- */
+
+/* Environment constants: the attributes ENV:17-89, 91-149, 194 that the step reads. */
+typedef struct asm_params {
+    int32_t n_a;                    /* ENV:92   agents per environment (1..1024) */
+    int32_t n_g_max;                /* row length of the per-env grid arrays (>= every n_g[e]) */
+    int32_t topo_nei_max;           /* ENV:33   must be 6 */
+    int32_t num_obs_grid_max;       /* ENV:126  80 */
+    int32_t num_occupied_grid_max;  /* ENV:128  200 */
+    int32_t is_boundary;            /* ENV:97-101  1: walls, 0: periodic arena */
+    int32_t is_con_self_state;      /* ENV:105  1: observation carries the agent's own p, dp */
+    int32_t compute_prior;          /* ENV:600  training_method == 'llm_rl' */
+    double size_a;                  /* ENV:43   0.035 */
+    double d_sen;                   /* ENV:194  0.4 */
+    double r_avoid;                 /* ENV:122 */
+    double vel_max;                 /* ENV:51   0.8 */
+    double k_ball, k_wall, c_wall;  /* ENV:70-73 30, 100, 5 */
+    double dt;                      /* ENV:78   0.1 */
+    double sensitivity;             /* ENV:80   1 */
+    double mass;                    /* ENV:39   1 */
+    double half_w, half_h;          /* ENV:63-64 2.4 */
+} asm_params;
+
+/* Fills the defaults listed above (r_avoid must still be set: ENV:121-122). */
+void asm_default_params(asm_params *prm, int n_a, int n_g_max);
+
+/* ENV:806: 2*dim*(topo_nei_max + 1 + self) + dim*num_obs_grid_max */
+int asm_obs_dim(const asm_params *prm);
+
+int asm_abi_version(void);
+const char *asm_last_error(void);
+/* Number of visible HIP devices, or a negative HIP error code. */
+int asm_device_count(void);
+
+/*
+ * Array layouts (all contiguous, device memory, E environments):
+ *   p, dp, act, a_prior  [E][2][n_a]        float   (component-major, as ENV's (2, n_a))
+ *   grid                 [E][2][n_g_max]    float   (ENV's grid_center (2, n_g), padded)
+ *   n_g                  [E]                int32
+ *   l_cell               [E]                double  (ENV:158)
+ *   neighbor_index       [E][n_a][6]        int32   -1 padded   (ENV:223)
+ *   in_flags             [E][n_a]           int32               (ENV:224)
+ *   nearest_cell         [E][n_a]           int32   index of the nearest grid cell
+ *   obs                  [E][obs_dim][n_a]  float   (ENV's (obs_dim, n_a) per env)
+ *   reward               [E][n_a]           float
+ *   sensed_index         [E][n_a][80]       int32   -1 padded   (ENV:225)  optional (NULL)
+ *   occupied_index       [E][n_a][200]      int32   -1 padded   (ENV:226)  optional (NULL)
+ *   stats                [E][8]             double  optional (NULL), accumulated (+=):
+ *        [0] sum of rewards  [1] sum of squared rewards  [2] coverage_rate
+ *        [3] distribution_uniformity  [4] contact pairs (pre-integration state)
+ *        [5] average_distance_to_target  [6] 1 (step count)  [7] agents inside the shape
+ *        (the per-step quantities TRAIN:128-135 accumulates; metrics of WRAP:48-165)
+ */
+
+/*
+ * Observation half of the step on a given state: what ENV.reset (ENV:216) and
+ * ENV.step (ENV:653-654) compute after the state is final.  Writes obs,
+ * neighbor_index, in_flags, nearest_cell (+ optional sensed/occupied, reward).
+ */
+int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const float *dp,
+                          const float *grid, const int32_t *n_g, const double *l_cell,
+                          int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
+                          float *obs, float *reward /*nullable*/, int32_t *sensed_index /*nullable*/,
+                          int32_t *occupied_index /*nullable*/, void *stream);
+
+/*
+ * One full step, ENV:482-661 with agent_strategy 'input', for E environments.
+ * In:  p, dp (updated in place), act, grid/n_g/l_cell, and the three arrays the
+ *      previous observation call left: neighbor_index, in_flags, nearest_cell
+ *      (the prior of CPP:1066-1123 is evaluated on the pre-integration state with
+ *      the previous neighbour list, ENV:607-619; its nearest-cell search is the one
+ *      the previous observation already did on that same state, so it is reused —
+ *      pass recompute_target != 0 if p or grid were changed since).
+ * Out: obs, reward, a_prior (NULL or compute_prior == 0: skipped), refreshed
+ *      neighbor_index / in_flags / nearest_cell, optional sensed/occupied/stats.
+ */
+int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const float *act,
+                       const float *grid, const int32_t *n_g, const double *l_cell,
+                       int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
+                       float *obs, float *reward, float *a_prior /*nullable*/,
+                       int32_t *sensed_index /*nullable*/, int32_t *occupied_index /*nullable*/,
+                       double *stats /*nullable*/, int recompute_target, void *stream);
+
+/*
+ * Batched reset, ENV:151-218: per environment a shape, a rotation, an offset and
+ * initial positions / velocities, drawn from Philox4x32-10 keyed by
+ * (seed, global environment id = env0 + e) with counter (draw index, episode), so
+ * any split of the id range over GPUs yields the same environments.
+ * Shapes: n_shapes canonical grids; grid k has shape_ng[k] cells stored as
+ * (x, y) rows starting at shape_grids + 2*shape_off[k] (the 'grid_coords' layout
+ * ENV:115 loads), cell size shape_lcell[k] — all device memory, doubles / int32.
+ * Writes shape_id, p, dp, grid, n_g, l_cell; then the observation of the new
+ * state exactly as asm_batch_observe_f32 (reward is not produced, ENV:216-218).
+ */
+int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, int64_t env0, int E,
+                        int n_shapes, const double *shape_grids, const int32_t *shape_off,
+                        const int32_t *shape_ng, const double *shape_lcell, int32_t *shape_id,
+                        float *p, float *dp, float *grid, int32_t *n_g, double *l_cell,
+                        int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
+                        float *obs, int32_t *sensed_index /*nullable*/,
+                        int32_t *occupied_index /*nullable*/, void *stream);
+
+/* U(-1,1) float32 actions from the same generator (ENV:519 'random' strategy):
+ * act[e][c][i] = draw (seed, env0+e, counter stream 1, step, c*n_a+i). */
+int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a,
+                                 float *act, void *stream);
+
+/* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the
+ * kernels rely on it being correctly rounded); n doubles, device pointers. */
+int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

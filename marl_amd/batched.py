@@ -1,0 +1,169 @@
+"""BatchedAssemblyEnv — E independent assembly environments stepped by one HIP
+kernel launch, behind the reset()/step() interface of the reference's
+AssemblySwarmEnv (cus_gym/gym/envs/customized_envs/assembly.py:151, 482).
+
+PyTorch is used for device memory and streams only; all environment arithmetic
+runs in libAssemblyEnv.so (marl_amd/csrc) through the C ABI.
+
+Tensor shapes keep the reference's per-environment layouts with a leading batch
+axis: obs (E, obs_dim, n_a), actions (E, 2, n_a), reward (E, 1, n_a),
+done (E, 1, n_a) all False, a_prior (E, 2, n_a).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .shapes import load_shapes
+
+
+def r_avoid_for(n_a: int, n_gs: Sequence[int], l_cells: Sequence[float]) -> float:
+    """assembly.py:121-122."""
+    return round(float(np.sqrt(4 * np.min(n_gs) / (n_a * np.pi)) * np.min(l_cells)), 2)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedAssemblyEnv:
+    def __init__(self, num_envs: int, n_a: int = 30, *, device="cuda", seed: int = 226, env_id_offset: int = 0,
+                 is_boundary: bool = True, is_con_self_state: bool = True, training_method: str = "llm_rl",
+                 shapes=None, r_avoid: Optional[float] = None, d_sen: float = 0.4, n_g_max: Optional[int] = None,
+                 keep_indices: bool = False, keep_stats: bool = True):
+        self.lib = _lib.load()
+        self.E = int(num_envs)
+        self.n_a = int(n_a)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchedAssemblyEnv runs on a HIP device only (device='cuda'); there is no CPU path")
+        self.seed = int(seed)
+        self.env_id_offset = int(env_id_offset)
+        self.episode = -1
+        self.step_count = 0
+        l_cells, grids = shapes if shapes is not None else load_shapes()
+        self.l_cells = list(l_cells)
+        self.grid_center_origins = [np.asarray(g, dtype=np.float64) for g in grids]
+        self.n_gs = [g.shape[0] for g in self.grid_center_origins]
+        self.num_train_shape = len(self.l_cells)
+        self.r_avoid = r_avoid if r_avoid is not None else r_avoid_for(self.n_a, self.n_gs, self.l_cells)
+        self.n_g_max = int(n_g_max) if n_g_max is not None else (max(self.n_gs) + 31) // 32 * 32
+        self.training_method = training_method
+        self.params = _lib.default_params(self.n_a, self.n_g_max, self.r_avoid, is_boundary=int(is_boundary),
+                                          is_con_self_state=int(is_con_self_state), d_sen=d_sen,
+                                          compute_prior=int(training_method == "llm_rl"))
+        self.obs_dim_agent = self.lib.asm_obs_dim(C.byref(self.params))
+        # spaces as the learner reads them (assembly.py:806-812; maddpg.py:264-266 reads .shape)
+        self.observation_space = SimpleNamespace(shape=(self.obs_dim_agent, self.n_a), dtype=np.float32)
+        self.action_space = SimpleNamespace(shape=(2, self.n_a), dtype=np.float32)
+        self.num_agents = self.n_a
+        self.agent_types = ["agent"]
+        self.alpha = 1
+
+        E, n, dev = self.E, self.n_a, self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.p = torch.zeros(E, 2, n, **f32)
+        self.dp = torch.zeros(E, 2, n, **f32)
+        self.grid_center = torch.zeros(E, 2, self.n_g_max, **f32)
+        self.n_g = torch.zeros(E, **i32)
+        self.l_cell = torch.zeros(E, dtype=torch.float64, device=dev)
+        self.shape_id = torch.zeros(E, **i32)
+        self.neighbor_index = torch.full((E, n, 6), -1, **i32)
+        self.in_flags = torch.zeros(E, n, **i32)
+        self.nearest_cell = torch.zeros(E, n, **i32)
+        self.obs = torch.zeros(E, self.obs_dim_agent, n, **f32)
+        self.reward = torch.zeros(E, 1, n, **f32)
+        self.a_prior = torch.zeros(E, 2, n, **f32)
+        self.done = torch.zeros(E, 1, n, dtype=torch.bool, device=dev)          # assembly.py:475-477
+        self.sensed_index = torch.full((E, n, 80), -1, **i32) if keep_indices else None
+        self.occupied_index = torch.full((E, n, 200), -1, **i32) if keep_indices else None
+        self.stats = torch.zeros(E, 8, dtype=torch.float64, device=dev) if keep_stats else None
+        # canonical shapes on the device (results.pkl 'grid_coords' layout, assembly.py:115)
+        off = np.zeros(self.num_train_shape, np.int32)
+        off[1:] = np.cumsum(self.n_gs)[:-1]
+        self._shape_grids = torch.from_numpy(np.concatenate(self.grid_center_origins, 0)).to(dev)
+        self._shape_off = torch.from_numpy(off).to(dev)
+        self._shape_ng = torch.tensor(self.n_gs, **i32)
+        self._shape_lcell = torch.tensor(self.l_cells, dtype=torch.float64, device=dev)
+        self._recompute_target = False
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, episode: Optional[int] = None) -> torch.Tensor:
+        """assembly.py:151-218 for every environment; returns obs (E, obs_dim, n_a)."""
+        self.episode = self.episode + 1 if episode is None else int(episode)
+        self.step_count = 0
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_reset_f32(
+                C.byref(self.params), self.seed, self.episode, self.env_id_offset, self.E, self.num_train_shape,
+                _ptr(self._shape_grids), _ptr(self._shape_off), _ptr(self._shape_ng), _ptr(self._shape_lcell),
+                _ptr(self.shape_id), _ptr(self.p), _ptr(self.dp), _ptr(self.grid_center), _ptr(self.n_g),
+                _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags), _ptr(self.nearest_cell),
+                _ptr(self.obs), _ptr(self.sensed_index), _ptr(self.occupied_index), self._stream())
+        _lib.check(rc, "asm_batch_reset_f32")
+        if self.stats is not None:
+            self.stats.zero_()
+        self._recompute_target = False
+        return self.obs
+
+    def observe(self, want_reward: bool = False) -> torch.Tensor:
+        """Recompute obs / neighbour lists / flags from the current tensors (after the
+        caller wrote p, dp, grid_center, n_g or l_cell directly)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_observe_f32(
+                C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), _ptr(self.grid_center), _ptr(self.n_g),
+                _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags), _ptr(self.nearest_cell),
+                _ptr(self.obs), _ptr(self.reward) if want_reward else None, _ptr(self.sensed_index),
+                _ptr(self.occupied_index), self._stream())
+        _lib.check(rc, "asm_batch_observe_f32")
+        self._recompute_target = False
+        return self.obs
+
+    def invalidate_target_cache(self) -> None:
+        """Call after changing p or the grid between steps without observe(): the next
+        step's prior then redoes its own nearest-cell search (AssemblyEnv.cpp:1107)."""
+        self._recompute_target = True
+
+    def step(self, a: torch.Tensor):
+        """assembly.py:482-661 ('input' strategy).  a: (E, 2, n_a) float32 on the device.
+        Returns (obs, reward, done, info, a_prior) like the reference's 5-tuple."""
+        if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.p.device or \
+                tuple(a.shape) != (self.E, 2, self.n_a):
+            raise ValueError(f"actions must be a contiguous float32 tensor of shape {(self.E, 2, self.n_a)} on {self.device}")
+        prior = self.a_prior if self.training_method == "llm_rl" else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_step_f32(
+                C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), _ptr(a), _ptr(self.grid_center),
+                _ptr(self.n_g), _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags),
+                _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior), _ptr(self.sensed_index),
+                _ptr(self.occupied_index), _ptr(self.stats), int(self._recompute_target), self._stream())
+        _lib.check(rc, "asm_batch_step_f32")
+        self._recompute_target = False
+        self.step_count += 1
+        return self.obs, self.reward, self.done, None, prior
+
+    def random_actions(self, out: Optional[torch.Tensor] = None, step: Optional[int] = None) -> torch.Tensor:
+        """U(-1,1) actions from the counter-based generator (assembly.py:519)."""
+        if out is None:
+            out = torch.empty(self.E, 2, self.n_a, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_random_actions_f32(self.seed, self.step_count if step is None else int(step),
+                                                       self.env_id_offset, self.E, self.n_a, _ptr(out), self._stream())
+        _lib.check(rc, "asm_batch_random_actions_f32")
+        return out
+
+    def episode_stats(self) -> torch.Tensor:
+        """[sum r, sum r^2, sum coverage, sum uniformity, sum contacts, sum avg-distance, steps, sum inside]
+        summed over this rank's environments (float64, 8 values) — the vector that is
+        all-reduced across GPUs once per episode."""
+        if self.stats is None:
+            raise RuntimeError("constructed with keep_stats=False")
+        return self.stats.sum(dim=0)

@@ -1,0 +1,376 @@
+// C ABI of libAssemblyEnv.so (declared in include/marl_amd_env.h): argument
+// checking, launch geometry, exact squared-distance thresholds, and the five
+// reference-compatible host-pointer entry points.  All arithmetic of the path runs
+// in the HIP kernels (asm_kernels.hip); nothing here computes environment results
+// on the CPU.
+#include "../../include/marl_amd_env.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "asm_kernels.h"
+
+using asmenv::DevParams;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+// min{ s >= 0 : fl(sqrt(s)) >= t }:  fl(sqrt(s)) < t  <=>  s < thr_lt(t)
+double thr_lt(double t)
+{
+    if (!(t > 0)) return 0.0;
+    double x = t * t;
+    while (std::sqrt(x) < t) x = std::nextafter(x, INFINITY);
+    for (;;) {
+        double y = std::nextafter(x, 0.0);
+        if (y < x && std::sqrt(y) >= t) x = y; else break;
+    }
+    return x;
+}
+// min{ s >= 0 : fl(sqrt(s)) > t }:  !(fl(sqrt(s)) > t)  <=>  s < thr_le(t)
+double thr_le(double t)
+{
+    if (t < 0) return 0.0;
+    double x = t * t;
+    while (std::sqrt(x) <= t) x = std::nextafter(x, INFINITY);
+    for (;;) {
+        double y = std::nextafter(x, 0.0);
+        if (y < x && std::sqrt(y) > t) x = y; else break;
+    }
+    return x;
+}
+
+int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// Launch geometry + thresholds.  state_bytes = sizeof(S).
+int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out)
+{
+    if (!prm) return fail(1, "asm_params is NULL");
+    if (E < 1) return fail(1, "E = %d: need at least one environment", E);
+    if (prm->n_a < 1 || prm->n_a > 1024) return fail(1, "n_a = %d: supported range is 1..1024", prm->n_a);
+    if (prm->topo_nei_max != 6) return fail(1, "topo_nei_max = %d: only 6 (ENV:33) is supported", prm->topo_nei_max);
+    if (prm->n_g_max < 1) return fail(1, "n_g_max = %d", prm->n_g_max);
+    if (prm->num_obs_grid_max < 2 || prm->num_occupied_grid_max < 2)
+        return fail(1, "num_obs_grid_max / num_occupied_grid_max must be >= 2");
+    DevParams P;
+    std::memset(&P, 0, sizeof P);
+    P.E = E; P.n_a = prm->n_a; P.n_g_max = prm->n_g_max;
+    P.SL = pow2_ceil(prm->n_a < 8 ? 8 : prm->n_a);
+    if (P.SL < 64) { P.block = 64; P.EPB = 64 / P.SL; } else { P.block = P.SL; P.EPB = 1; }
+    P.grid = (E + P.EPB - 1) / P.EPB;
+    P.NGP = (prm->n_g_max + 31) / 32 * 32;
+    P.W = P.NGP / 32;
+    P.MW = (P.W | 1) < 9 ? 9 : (P.W | 1);
+    size_t env_bytes = state_bytes * (4 * (size_t)P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.SL * P.MW + 2 * (size_t)P.W);
+    env_bytes = (env_bytes + 15) / 16 * 16;
+    P.lds_env_bytes = (unsigned)env_bytes;
+    P.lds_block_bytes = (unsigned)(env_bytes * P.EPB);
+    if (P.lds_block_bytes > 160 * 1024)
+        return fail(1, "n_a = %d with n_g_max = %d needs %u bytes of LDS per workgroup (> 160 KiB)", prm->n_a,
+                    prm->n_g_max, P.lds_block_bytes);
+    P.topo = 6; P.n_obs = prm->num_obs_grid_max; P.n_occ = prm->num_occupied_grid_max;
+    P.con_self = prm->is_con_self_state != 0; P.cartesian = 1;
+    P.obs_dim = 2 * 2 * (6 + 1 + (P.con_self ? 1 : 0)) + 2 * P.n_obs;      // ENV:806
+    P.periodic = prm->is_boundary ? 0 : 1;
+    P.prior = prm->compute_prior != 0;
+    P.d_sen = prm->d_sen; P.r_avoid = prm->r_avoid; P.size_a = prm->size_a; P.sizes2 = prm->size_a + prm->size_a;
+    P.vel_max = prm->vel_max; P.k_ball = prm->k_ball; P.k_wall = prm->k_wall; P.c_wall = prm->c_wall;
+    P.dt = prm->dt; P.sens = prm->sensitivity; P.mass = prm->mass; P.half_w = prm->half_w; P.half_h = prm->half_h;
+    P.T_sen = thr_lt(P.d_sen);
+    P.T_half_le = thr_le(P.r_avoid / 2.0);
+    P.T_half_lt = thr_lt(P.r_avoid / 2);
+    P.T_ravoid = thr_lt(P.r_avoid);
+    P.T_contact = thr_lt(P.sizes2);
+    P.T_v005 = thr_lt(0.05);
+    *out = P;
+    return 0;
+}
+
+int hip_fail(int rc, const char *what)
+{
+    return fail(rc, "%s: HIP error %d (%s)", what, rc, hipGetErrorString((hipError_t)rc));
+}
+
+// ---- workspace + helpers for the five host-pointer entry points -----------------
+std::mutex g_compat_mutex;
+unsigned char *g_ws = nullptr;
+size_t g_ws_bytes = 0;
+
+[[noreturn]] void die(const char *what, hipError_t e)
+{
+    std::fprintf(stderr, "libAssemblyEnv (HIP): %s failed: %s. This library has no CPU fallback.\n", what,
+                 hipGetErrorString(e));
+    std::abort();
+}
+#define HIP_OR_DIE(call) do { hipError_t _e = (call); if (_e != hipSuccess) die(#call, _e); } while (0)
+
+struct Arena {
+    size_t off = 0;
+    template <typename T> size_t take(size_t n) { size_t o = off; off += (n * sizeof(T) + 255) / 256 * 256; return o; }
+};
+void ensure_ws(size_t bytes)
+{
+    if (bytes <= g_ws_bytes) return;
+    if (g_ws) HIP_OR_DIE(hipFree(g_ws));
+    HIP_OR_DIE(hipMalloc((void **)&g_ws, bytes));
+    g_ws_bytes = bytes;
+}
+template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(g_ws + off); }
+template <typename T> void h2d(size_t off, const T *src, size_t n) { HIP_OR_DIE(hipMemcpy(g_ws + off, src, n * sizeof(T), hipMemcpyHostToDevice)); }
+template <typename T> void d2h(T *dst, size_t off, size_t n) { HIP_OR_DIE(hipMemcpy(dst, g_ws + off, n * sizeof(T), hipMemcpyDeviceToHost)); }
+
+void compat_params(asm_params *a, int n_a, int n_g, int topo, int n_obs, int n_occ, double d_sen, double r_avoid,
+                   const double *bpos)
+{
+    asm_default_params(a, n_a, n_g);
+    a->topo_nei_max = topo; a->num_obs_grid_max = n_obs; a->num_occupied_grid_max = n_occ;
+    a->d_sen = d_sen; a->r_avoid = r_avoid;
+    if (bpos) { a->half_w = (bpos[2] - bpos[0]) / 2.0; a->half_h = (bpos[1] - bpos[3]) / 2.0; }   // CPP:75-76
+}
+
+[[noreturn]] void die_msg(const char *fn)
+{
+    std::fprintf(stderr, "libAssemblyEnv (HIP): %s: %s\n", fn, g_err.c_str());
+    std::abort();
+}
+
+}  // namespace
+
+extern "C" {
+
+void asm_default_params(asm_params *p, int n_a, int n_g_max)
+{
+    std::memset(p, 0, sizeof *p);
+    p->n_a = n_a; p->n_g_max = n_g_max; p->topo_nei_max = 6; p->num_obs_grid_max = 80;
+    p->num_occupied_grid_max = 200; p->is_boundary = 1; p->is_con_self_state = 1; p->compute_prior = 1;
+    p->size_a = 0.035; p->d_sen = 0.4; p->r_avoid = 0.26; p->vel_max = 0.8; p->k_ball = 30; p->k_wall = 100;
+    p->c_wall = 5; p->dt = 0.1; p->sensitivity = 1; p->mass = 1; p->half_w = 2.4; p->half_h = 2.4;
+}
+
+int asm_obs_dim(const asm_params *p)
+{
+    return 2 * 2 * (p->topo_nei_max + 1 + (p->is_con_self_state ? 1 : 0)) + 2 * p->num_obs_grid_max;
+}
+
+int asm_abi_version(void) { return ASM_ABI_VERSION; }
+const char *asm_last_error(void) { return g_err.c_str(); }
+
+int asm_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail((int)e, "hipGetDeviceCount: %s", hipGetErrorString(e)); return -(int)e; }
+    return n;
+}
+
+int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const float *dp, const float *grid,
+                          const int32_t *n_g, const double *l_cell, int32_t *neighbor_index, int32_t *in_flags,
+                          int32_t *nearest_cell, float *obs, float *reward, int32_t *sensed_index,
+                          int32_t *occupied_index, void *stream)
+{
+    DevParams P;
+    if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
+    if (!p || !dp || !grid || !n_g || !l_cell || !neighbor_index || !in_flags || !nearest_cell || !obs)
+        return fail(1, "asm_batch_observe_f32: NULL required pointer");
+    P.want_reward = reward != nullptr;
+    int rc = asmenv::launch_observe<float>(P, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags,
+                                           nearest_cell, obs, reward, sensed_index, occupied_index,
+                                           (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_observe_f32") : 0;
+}
+
+int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const float *act, const float *grid,
+                       const int32_t *n_g, const double *l_cell, int32_t *neighbor_index, int32_t *in_flags,
+                       int32_t *nearest_cell, float *obs, float *reward, float *a_prior, int32_t *sensed_index,
+                       int32_t *occupied_index, double *stats, int recompute_target, void *stream)
+{
+    DevParams P;
+    if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
+    if (!p || !dp || !act || !grid || !n_g || !l_cell || !neighbor_index || !in_flags || !nearest_cell || !obs || !reward)
+        return fail(1, "asm_batch_step_f32: NULL required pointer");
+    P.want_reward = 1; P.want_stats = stats != nullptr; P.recompute = recompute_target != 0;
+    if (!a_prior) P.prior = 0;
+    int rc = asmenv::launch_step<float>(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+                                        reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_step_f32") : 0;
+}
+
+int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, int64_t env0, int E, int n_shapes,
+                        const double *shape_grids, const int32_t *shape_off, const int32_t *shape_ng,
+                        const double *shape_lcell, int32_t *shape_id, float *p, float *dp, float *grid, int32_t *n_g,
+                        double *l_cell, int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell, float *obs,
+                        int32_t *sensed_index, int32_t *occupied_index, void *stream)
+{
+    DevParams P;
+    if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
+    if (n_shapes < 1) return fail(1, "asm_batch_reset_f32: n_shapes = %d", n_shapes);
+    if (!shape_grids || !shape_off || !shape_ng || !shape_lcell || !shape_id || !p || !dp || !grid || !n_g || !l_cell ||
+        !neighbor_index || !in_flags || !nearest_cell || !obs)
+        return fail(1, "asm_batch_reset_f32: NULL required pointer");
+    int rc = asmenv::launch_reset<float>(P, seed, episode, env0, n_shapes, shape_grids, shape_off, shape_ng,
+                                         shape_lcell, shape_id, p, dp, grid, n_g, l_cell, neighbor_index, in_flags,
+                                         nearest_cell, obs, sensed_index, occupied_index, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_reset_f32") : 0;
+}
+
+int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, void *stream)
+{
+    if (E < 1 || n_a < 1 || !act) return fail(1, "asm_batch_random_actions_f32: bad arguments");
+    int rc = asmenv::launch_random_actions(seed, step, env0, E, n_a, act, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_random_actions_f32") : 0;
+}
+
+int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream)
+{
+    if (n < 1 || !in || !out) return fail(1, "asm_debug_sqrt_f64: bad arguments");
+    int rc = asmenv::launch_sqrt(in, out, n, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_debug_sqrt_f64") : 0;
+}
+
+// ------------------------------------------------------------------------------
+// The five reference entry points: host pointers in, GPU compute, host pointers out.
+
+void _get_observation(double *p_in, double *dp_in, double *heading_in, double *obs_io, double *bpos, double *grid_in,
+                      int *nbr_io, int *inflags_io, int *sensed_io, int *occupied_io, double d_sen, double r_avoid,
+                      double l_cell, double Vel_max, int topo_nei_max, int num_obs_grid_max,
+                      int num_occupied_grid_max, int n_a, int n_g, int obs_dim_agent, int dim, bool *condition)
+{
+    (void)Vel_max;                                           // unused by the reference too (CPP:36)
+    std::lock_guard<std::mutex> lk(g_compat_mutex);
+    if (dim != 2) { fail(1, "dim = %d: only 2 is supported", dim); die_msg("_get_observation"); }
+    asm_params a; compat_params(&a, n_a, n_g, topo_nei_max, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
+    a.is_boundary = condition[0] ? 0 : 1; a.is_con_self_state = condition[2] ? 1 : 0;
+    DevParams P;
+    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("_get_observation");
+    P.cartesian = condition[1] ? 1 : 0;
+    P.obs_dim = obs_dim_agent;
+    const int min_rows = (P.con_self ? 4 : 0) + 24 + (P.cartesian ? 4 + 2 * P.n_obs : 6);
+    if (obs_dim_agent < min_rows) { fail(1, "obs_dim_agent = %d < %d", obs_dim_agent, min_rows); die_msg("_get_observation"); }
+    const size_t na = (size_t)n_a, ng = (size_t)n_g;
+    Arena A;
+    size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_h = A.take<double>(2 * na);
+    size_t o_g = A.take<double>(2 * ng), o_ng = A.take<int>(1), o_lc = A.take<double>(1);
+    size_t o_obs = A.take<double>((size_t)obs_dim_agent * na), o_nbr = A.take<int>(na * 6), o_in = A.take<int>(na);
+    size_t o_near = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_occ = A.take<int>(na * P.n_occ);
+    ensure_ws(A.off);
+    h2d(o_p, p_in, 2 * na); h2d(o_dp, dp_in, 2 * na); h2d(o_h, heading_in, 2 * na); h2d(o_g, grid_in, 2 * ng);
+    h2d(o_ng, &n_g, 1); h2d(o_lc, &l_cell, 1);
+    HIP_OR_DIE(hipMemset(g_ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double)));   // CPP:49 zero-initialised
+    int rc = asmenv::launch_observe<double>(P, at<double>(o_p), at<double>(o_dp), at<double>(o_h), at<double>(o_g),
+                                            at<int>(o_ng), at<double>(o_lc), at<int>(o_nbr), at<int>(o_in),
+                                            at<int>(o_near), at<double>(o_obs), nullptr, at<int>(o_sen),
+                                            at<int>(o_occ), nullptr);
+    if (rc) die("_get_observation kernel launch", (hipError_t)rc);
+    HIP_OR_DIE(hipDeviceSynchronize());
+    d2h(obs_io, o_obs, (size_t)obs_dim_agent * na); d2h(nbr_io, o_nbr, na * 6); d2h(inflags_io, o_in, na);
+    d2h(sensed_io, o_sen, na * P.n_obs); d2h(occupied_io, o_occ, na * P.n_occ);
+}
+
+void _get_reward(double *p_in, double *dp_in, double *heading_in, double *act_in, double *reward_io, double *bpos,
+                 double *grid_in, int *nbr_in, int *inflags_in, int *sensed_in, int *occupied_in, double d_sen,
+                 double r_avoid, double l_cell, int topo_nei_max, int num_obs_grid_max, int num_occupied_grid_max,
+                 int n_a, int n_g, int dim, bool *condition, bool *is_collide_b2b, bool *is_collide_b2w,
+                 double *coefficients)
+{
+    // dp, heading, act, occupied_index, l_cell, the contact matrices and the coefficients are
+    // copied but never read by the reference either (CPP:384-452 vs 457-564).
+    (void)dp_in; (void)heading_in; (void)act_in; (void)occupied_in; (void)l_cell; (void)is_collide_b2b;
+    (void)is_collide_b2w; (void)coefficients; (void)dim;
+    std::lock_guard<std::mutex> lk(g_compat_mutex);
+    asm_params a; compat_params(&a, n_a, n_g, 6, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
+    DevParams P;
+    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("_get_reward");
+    if (topo_nei_max < 1) { fail(1, "topo_nei_max = %d", topo_nei_max); die_msg("_get_reward"); }
+    P.topo = topo_nei_max;
+    const size_t na = (size_t)n_a, ng = (size_t)n_g;
+    Arena A;
+    size_t o_p = A.take<double>(2 * na), o_g = A.take<double>(2 * ng), o_nbr = A.take<int>(na * topo_nei_max);
+    size_t o_in = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_r = A.take<double>(na);
+    ensure_ws(A.off);
+    h2d(o_p, p_in, 2 * na); h2d(o_g, grid_in, 2 * ng); h2d(o_nbr, nbr_in, na * topo_nei_max);
+    h2d(o_in, inflags_in, na); h2d(o_sen, sensed_in, na * P.n_obs);
+    int rc = asmenv::launch_reward_compat(P, at<double>(o_p), at<double>(o_g), n_g, at<int>(o_nbr), at<int>(o_in),
+                                          at<int>(o_sen), condition[0], condition[3], condition[4], at<double>(o_r),
+                                          nullptr);
+    if (rc) die("_get_reward kernel launch", (hipError_t)rc);
+    HIP_OR_DIE(hipDeviceSynchronize());
+    d2h(reward_io, o_r, na);
+}
+
+void _sf_b2b_all(double *p_in, double *sf_io, double *d_edge_in, bool *collide_in, double *bpos, double *d_center_in,
+                 int n_a, int dim, double k_ball, bool is_periodic)
+{
+    (void)dim;
+    std::lock_guard<std::mutex> lk(g_compat_mutex);
+    if (n_a < 1) return;
+    const size_t na = (size_t)n_a;
+    Arena A;
+    size_t o_p = A.take<double>(2 * na), o_de = A.take<double>(na * na), o_dc = A.take<double>(na * na);
+    size_t o_c = A.take<bool>(na * na), o_sf = A.take<double>(2 * na);
+    ensure_ws(A.off);
+    h2d(o_p, p_in, 2 * na); h2d(o_de, d_edge_in, na * na); h2d(o_dc, d_center_in, na * na); h2d(o_c, collide_in, na * na);
+    const double hw = (bpos[2] - bpos[0]) / 2.0, hh = (bpos[1] - bpos[3]) / 2.0;                   // CPP:776-777
+    int rc = asmenv::launch_sf_b2b_compat(at<double>(o_p), at<double>(o_de), at<bool>(o_c), at<double>(o_dc), n_a,
+                                          k_ball, is_periodic, hw, hh, at<double>(o_sf), nullptr);
+    if (rc) die("_sf_b2b_all kernel launch", (hipError_t)rc);
+    HIP_OR_DIE(hipDeviceSynchronize());
+    d2h(sf_io, o_sf, 2 * na);
+}
+
+void _get_dist_b2w(double *p_in, double *r_in, double *d_b2w_io, bool *coll_io, int dim, int n_a, double *bpos)
+{
+    (void)dim;
+    std::lock_guard<std::mutex> lk(g_compat_mutex);
+    if (n_a < 1) return;
+    const size_t na = (size_t)n_a;
+    Arena A;
+    size_t o_p = A.take<double>(2 * na), o_r = A.take<double>(na), o_d = A.take<double>(4 * na), o_c = A.take<bool>(4 * na);
+    ensure_ws(A.off);
+    h2d(o_p, p_in, 2 * na); h2d(o_r, r_in, na);
+    int rc = asmenv::launch_dist_b2w_compat(at<double>(o_p), at<double>(o_r), n_a, bpos, at<double>(o_d), at<bool>(o_c),
+                                            nullptr);
+    if (rc) die("_get_dist_b2w kernel launch", (hipError_t)rc);
+    HIP_OR_DIE(hipDeviceSynchronize());
+    d2h(d_b2w_io, o_d, 4 * na); d2h(coll_io, o_c, 4 * na);
+}
+
+void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, double *grid_in, int *nbr_in, double d_sen,
+                          double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim)
+{
+    (void)dim;
+    std::lock_guard<std::mutex> lk(g_compat_mutex);
+    asm_params a; compat_params(&a, n_a, n_g, 6, 80, 200, d_sen, r_avoid, nullptr);
+    DevParams P;
+    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("calculateActionPrior");
+    if (topo_nei_max < 1 || topo_nei_max > 6) { fail(1, "topo_nei_max = %d: supported 1..6", topo_nei_max); die_msg("calculateActionPrior"); }
+    P.topo = topo_nei_max;
+    const size_t na = (size_t)n_a, ng = (size_t)n_g;
+    Arena A;
+    size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_g = A.take<double>(2 * ng);
+    size_t o_nbr = A.take<int>(na * topo_nei_max), o_a = A.take<double>(2 * na);
+    ensure_ws(A.off);
+    h2d(o_p, p_in, 2 * na); h2d(o_dp, dp_in, 2 * na); h2d(o_g, grid_in, 2 * ng); h2d(o_nbr, nbr_in, na * topo_nei_max);
+    int rc = asmenv::launch_prior_compat(P, at<double>(o_p), at<double>(o_dp), at<double>(o_g), n_g, at<int>(o_nbr),
+                                         l_cell, at<double>(o_a), nullptr);
+    if (rc) die("calculateActionPrior kernel launch", (hipError_t)rc);
+    HIP_OR_DIE(hipDeviceSynchronize());
+    d2h(a_prior_io, o_a, 2 * na);
+}
+
+}  // extern "C"

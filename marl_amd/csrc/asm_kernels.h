@@ -1,0 +1,54 @@
+// Internal interface between the C-ABI layer (asm_capi.cpp) and the HIP kernels
+// (asm_kernels.hip).  Not installed; the public interface is include/marl_amd_env.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace asmenv {
+
+// Kernel parameters, passed by value.  The T_* members are squared-distance
+// thresholds: for a threshold t of the reference, T = min{ s : fl(sqrt(s)) >= t } so that
+// fl(sqrt(s)) < t  <=>  s < T exactly (T_*_le: min{ s : fl(sqrt(s)) > t }, so that
+// !(fl(sqrt(s)) > t) <=> s < T).
+struct DevParams {
+    int E, n_a, SL, EPB, n_g_max, NGP, W, MW;
+    int topo, n_obs, n_occ, obs_dim;
+    int periodic, cartesian, con_self, prior, recompute, want_reward, want_stats;
+    int n_g_e;                      // set per environment inside the kernels
+    int block, grid;
+    unsigned lds_env_bytes, lds_block_bytes;
+    double T_sen;                   // norm < d_sen            CPP:663, 907
+    double T_half_le;               // !(norm > r_avoid/2)     CPP:190
+    double T_half_lt;               // norm < r_avoid/2        WRAP:67
+    double T_ravoid;                // norm < r_avoid          CPP:487, 1171
+    double T_contact;               // norm - 2*size_a < 0     ENV:445-446
+    double T_v005;                  // norm < 0.05             CPP:552
+    double d_sen, r_avoid, sizes2, size_a, vel_max, k_ball, k_wall, c_wall, dt, sens, mass, half_w, half_h;
+};
+
+template <typename S>
+int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading, const S *grid, const int *n_g,
+                   const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, int *sensed,
+                   int *occupied, hipStream_t st);
+template <typename S>
+int launch_step(const DevParams &P, S *p, S *dp, const float *act, const S *grid, const int *n_g,
+                const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
+                int *occupied, double *stats, hipStream_t st);
+template <typename S>
+int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
+                 const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,
+                 int *shape_id, S *p, S *dp, S *grid, int *n_g, double *l_cell, int *nbr, int *inflags, int *nearest,
+                 S *obs, int *sensed, int *occupied, hipStream_t st);
+int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st);
+int launch_sqrt(const double *in, double *out, int n, hipStream_t st);
+int launch_reward_compat(const DevParams &P, const double *p, const double *grid, int n_g, const int *nbr,
+                         const int *inflags, const int *sensed, bool c_periodic, bool c_interaction,
+                         bool c_exploration, double *reward, hipStream_t st);
+int launch_sf_b2b_compat(const double *p, const double *d_edge, const bool *collide, const double *d_center, int n_a,
+                         double k_ball, bool periodic, double hw, double hh, double *sf, hipStream_t st);
+int launch_dist_b2w_compat(const double *p, const double *r, int n_a, const double *bpos_host, double *d_b2w,
+                           bool *coll, hipStream_t st);
+int launch_prior_compat(const DevParams &P, const double *p, const double *dp, const double *grid, int n_g,
+                        const int *nbr, double l_cell, double *a_prior, hipStream_t st);
+
+}  // namespace asmenv

@@ -1,0 +1,814 @@
+// HIP kernels (gfx950) for the assembly-environment step path.
+//
+// Reference algorithm (cited per block):
+//   CPP = cus_gym/gym/envs/customized_envs/envs_cplus/src/AssemblyEnv.cpp
+//   ENV = cus_gym/gym/envs/customized_envs/assembly.py
+//
+// Mapping: one lane per agent.  An environment owns SL consecutive lanes
+// (SL = power of two >= n_a); a workgroup holds EPB = block/SL environments
+// (two 30-agent environments per 64-lane wavefront; one 1024-agent environment per
+// 16-wave workgroup).  Per environment the workgroup keeps positions, velocities,
+// the transformed target grid, one sensed-cell bitmask per agent and two per-cell
+// occupancy bitmaps in LDS, so HBM sees each input once and each output once.
+//
+// Numerics: the state is stored as S (float for the batched path, double for the
+// five reference-compatible entry points).  Every DECISION of the reference is a
+// strict comparison on a double-precision distance (CPP:663, 894, 907, 166, 190,
+// 487, 552, 1171; ENV:446; CPP:849).  They are evaluated here in double on the
+// stored state, un-fused (this file is compiled with -ffp-contract=off), with
+// sqrt(s) < t rewritten as s < T(t) where T(t) is the exact preimage boundary of the
+// correctly rounded square root (computed on the host, asm_capi.cpp).  Fed the same
+// numbers, the kernels therefore take the same branches and produce the same
+// indices as the reference; values are rounded once to S on output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asm_kernels.h"
+
+namespace asmenv {
+
+#define ASM_PI 3.14159265358979323846
+
+__device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double hh)
+{   // CPP:705-720
+    if (x < -hw) x += 2 * hw; else if (x > hw) x -= 2 * hw;
+    if (y < -hh) y += 2 * hh; else if (y > hh) y -= 2 * hh;
+}
+
+// ---- Philox4x32-10 (same generator as the CPU oracle) ------------------------
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t m0 = (uint64_t)0xD2511F53u * c0, m1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(m1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)m1;
+        uint32_t n2 = (uint32_t)(m0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)m0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ uint32_t draw_u32(uint64_t seed, uint64_t env, uint32_t c1, uint32_t c2, uint32_t d)
+{
+    uint32_t o[4];
+    philox4x32(d >> 2, c1, c2, 0u, (uint32_t)env, (uint32_t)seed ^ (uint32_t)(env >> 32), o);
+    return o[d & 3u];
+}
+__device__ __forceinline__ double draw_uniform(uint64_t seed, uint64_t env, uint32_t ep, uint32_t d, double lo, double hi)
+{
+    double u = (double)draw_u32(seed, env, ep, 0u, d) * (1.0 / 4294967296.0);
+    return lo + (hi - lo) * u;
+}
+
+// ---- LDS carve ------------------------------------------------------------------
+template <typename S>
+struct EnvLds {
+    S *px, *py, *vx, *vy, *gx, *gy;
+    unsigned *mask, *occ, *cov;
+};
+
+template <typename S>
+__device__ __forceinline__ EnvLds<S> carve(unsigned char *base, const DevParams &P, int es)
+{
+    unsigned char *b = base + (size_t)es * P.lds_env_bytes;
+    EnvLds<S> L;
+    S *f = reinterpret_cast<S *>(b);
+    L.px = f; L.py = f + P.SL; L.vx = f + 2 * P.SL; L.vy = f + 3 * P.SL;
+    L.gx = f + 4 * P.SL; L.gy = L.gx + P.NGP;
+    unsigned *u = reinterpret_cast<unsigned *>(L.gy + P.NGP);
+    L.mask = u; L.occ = u + (size_t)P.SL * P.MW; L.cov = L.occ + P.W;
+    return L;
+}
+
+// ---- iteration over the set bits of a per-agent cell mask, ascending ----------
+struct BitIter {
+    const unsigned *words; int w; int W; unsigned bits; const unsigned *andw; bool inv;
+    __device__ __forceinline__ unsigned load(int k) const
+    {
+        unsigned v = words[k];
+        if (andw) v &= inv ? ~andw[k] : andw[k];
+        return v;
+    }
+    __device__ __forceinline__ void init(const unsigned *m, int W_, const unsigned *a, bool inv_)
+    { words = m; W = W_; andw = a; inv = inv_; w = 0; bits = load(0); }
+    __device__ __forceinline__ int next()
+    {
+        while (bits == 0) { if (++w >= W) return -1; bits = load(w); }
+        int b = __ffs(bits) - 1; bits &= bits - 1;
+        return w * 32 + b;
+    }
+};
+
+// CPP:1126-1201 robotPolicy, given the target position
+template <typename S>
+__device__ __forceinline__ void prior_policy(const DevParams &P, double px, double py, double vx, double vy,
+                                             double tx, double ty, const int *nbr, const S *X, const S *Y,
+                                             const S *VX, const S *VY, double &f0, double &f1)
+{
+    f0 = 0.0; f1 = 0.0;
+    double d0 = tx - px, d1 = ty - py;                                   // CPP:1147
+    double dist = sqrt(d0 * d0 + d1 * d1);                               // CPP:1148
+    if (dist > 0) { f0 += 2.0 * d0 / dist; f1 += 2.0 * d1 / dist; }      // CPP:1150-1153
+    double av0 = 0.0, av1 = 0.0; int cnt = 0;
+    for (int k = 0; k < P.topo; ++k) {
+        int j = nbr[k];
+        if (j == -1) continue;                                           // CPP:1219-1227
+        double n0 = px - (double)X[j], n1 = py - (double)Y[j];           // CPP:1167
+        double s = n0 * n0 + n1 * n1;
+        if (s > 0 && s < P.T_ravoid) {                                   // CPP:1171 (dn > 0 && dn < r_avoid)
+            double dn = sqrt(s);
+            double u0 = n0 / dn, u1 = n1 / dn;
+            double factor = 3.0 * (P.r_avoid / dn - 1.0);                // CPP:1176
+            f0 += factor * u0; f1 += factor * u1;
+        }
+        av0 += (double)VX[j]; av1 += (double)VY[j]; ++cnt;               // CPP:1182-1184
+    }
+    if (cnt > 0) {
+        av0 /= cnt; av1 /= cnt;                                          // CPP:1189-1190
+        f0 += 2.0 * (av0 - vx); f1 += 2.0 * (av1 - vy);                  // CPP:1192-1193
+    }
+    f0 = fmax(-1.0, fmin(f0, 1.0)); f1 = fmax(-1.0, fmin(f1, 1.0));      // CPP:1197-1198
+}
+
+// Nearest cell (first minimum, CPP:889) of agent at (px,py) over grid arrays; optionally
+// builds the sensed mask (CPP:905-910) and the per-cell occupancy bitmaps.
+template <typename S, bool MASKS>
+__device__ __forceinline__ void cell_pass(const DevParams &P, bool active, double px, double py, const S *gx,
+                                          const S *gy, int i, unsigned *mask, unsigned *occ, unsigned *cov,
+                                          double &smin, int &imin)
+{
+    smin = __builtin_inf(); imin = 0;
+    for (int w = 0; w < P.W; ++w) {
+        unsigned word = 0;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const int c = w * 32 + b;
+            double rx = (double)gx[c] - px, ry = (double)gy[c] - py;     // CPP:876-877
+            double s = rx * rx + ry * ry;                                // CPP:885 (norm squared)
+            if (s < smin) { smin = s; imin = c; }
+            if (MASKS) {
+                word |= (s < P.T_sen ? 1u : 0u) << b;                    // CPP:907  norm < d_sen
+                if (active && s < P.T_half_le) {                         // CPP:190  !(norm > r_avoid/2)
+                    atomicOr(&occ[w], 1u << b);
+                    if (s < P.T_half_lt) atomicOr(&cov[w], 1u << b);     // WRAP:67  norm < r_avoid/2
+                }
+            }
+        }
+        if (MASKS) mask[(size_t)i * P.MW + w] = word;
+    }
+}
+
+// Uniform-subsampled emission of a bit list: for k in [0, cap): f(k, cell or -1).
+// count <= cap: the k-th set bit; count > cap: bit number round(k*(count-1)/(cap-1))
+// (CPP:224-229, 246-251; std::round, half away from zero).
+template <typename F>
+__device__ __forceinline__ void emit_list(BitIter &it, int count, int cap, F f)
+{
+    const int n_out = count < cap ? count : cap;
+    const double step = count > cap ? (double)(count - 1) / (cap - 1) : 1.0;
+    int rank = -1, cell = -1;
+    for (int k = 0; k < cap; ++k) {
+        if (k < n_out) {
+            int target = count > cap ? (int)round(k * step) : k;
+            while (rank < target) { cell = it.next(); ++rank; }
+            f(k, cell);
+        } else {
+            f(k, -1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Observation + reward of environment e for agent i on the state held in LDS.
+// CPP:23-356 (observation), CPP:359-631 (reward).  Must be reached by every thread.
+template <typename S>
+__device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, double l_cell,
+                        const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
+                        int *sensed_g, int *occup_g, double *stats_g, int contact_pairs)
+{
+    const int n_a = P.n_a;
+    const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
+    const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
+    S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
+
+    // ---- k nearest neighbours inside d_sen: _get_focused, CPP:633-703 ----
+    double s6[6]; int j6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
+    double nn_min = __builtin_inf();
+    if (active) {
+        for (int j = 0; j < n_a; ++j) {
+            double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py; // CPP:84
+            if (P.want_stats) { double su = rx * rx + ry * ry; if (su != 0 && su < nn_min) nn_min = su; }
+            if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
+            double s = rx * rx + ry * ry;                                // CPP:641
+            if (j != i && s < P.T_sen) {                                 // CPP:663, self removed CPP:677-681
+                double ks = s; int kj = j;
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    if (ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+            }
+        }
+        // agent block, column-major flatten of rows [pos_x,pos_y,vel_x,vel_y] (CPP:108-131)
+        int r0 = 0;
+        if (P.con_self) {
+            ocol[0] = (S)px; ocol[(size_t)n_a] = (S)py; ocol[(size_t)2 * n_a] = (S)vx; ocol[(size_t)3 * n_a] = (S)vy;
+            r0 = 4;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int j = j6[q];
+            double rx = 0, ry = 0, wx = 0, wy = 0;
+            if (j >= 0) {
+                rx = (double)L.px[j] - px; ry = (double)L.py[j] - py;
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (P.cartesian) { wx = (double)L.vx[j] - vx; wy = (double)L.vy[j] - vy; }   // CPP:86
+                else {                                                                       // CPP:88
+                    wx = (double)heading_g[j] - (double)heading_g[i];
+                    wy = (double)heading_g[n_a + j] - (double)heading_g[n_a + i];
+                }
+            }
+            nbr_g[((size_t)e * n_a + i) * 6 + q] = j;                    // CPP:103-105
+            size_t r = (size_t)(r0 + 4 * q) * n_a;
+            ocol[r] = (S)rx; ocol[r + n_a] = (S)ry; ocol[r + 2 * (size_t)n_a] = (S)wx; ocol[r + 3 * (size_t)n_a] = (S)wy;
+        }
+    }
+
+    // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
+    for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
+    __syncthreads();
+    double smin; int imin;
+    cell_pass<S, true>(P, active, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
+    const double dmin = sqrt(smin);
+    const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
+    __syncthreads();
+
+    unsigned *mym = L.mask + (size_t)i * P.MW;
+    int n_before = 0, n_after = 0, n_occ = 0;
+    if (active) {
+        for (int w = 0; w < P.W; ++w) {
+            unsigned m = mym[w];
+            n_before += __popc(m);
+            if (in_flag) { n_occ += __popc(m & L.occ[w]); }              // CPP:155: only when inside the shape
+        }
+        n_after = n_before - n_occ;
+        inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;                 // CPP:139
+        nearest_g[(size_t)e * n_a + i] = imin;
+
+        // target block (CPP:141-142, 896-901)
+        double t0, t1, t2, t3;
+        if (in_flag) { t0 = px - px; t1 = py - py; t2 = vx - vx; t3 = vy - vy; }
+        else { t0 = (double)L.gx[imin] - px; t1 = (double)L.gy[imin] - py; t2 = 0.0 - vx; t3 = 0.0 - vy; }
+        const int tb = P.cartesian ? P.obs_dim - (2 + P.n_obs) * 2 : P.obs_dim - 6;   // CPP:304, 317
+        ocol[(size_t)(tb + 0) * n_a] = (S)t0; ocol[(size_t)(tb + 1) * n_a] = (S)t1;
+        ocol[(size_t)(tb + 2) * n_a] = (S)t2; ocol[(size_t)(tb + 3) * n_a] = (S)t3;
+        if (!P.cartesian) {                                              // CPP:322-324
+            ocol[(size_t)(tb + 4) * n_a] = heading_g[i]; ocol[(size_t)(tb + 5) * n_a] = heading_g[n_a + i];
+        }
+
+        // occupied list = sensed_before \ sensed_after (CPP:215-238)
+        if (occup_g) {
+            int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
+            BitIter it; it.init(mym, P.W, L.occ, false);
+            emit_list(it, n_occ, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+        }
+    }
+
+    // ---- sensed list (CPP:243-296) and exploration reward terms (CPP:499-557) ----
+    double num0 = 0.0, num1 = 0.0, den = 0.0;
+    if (active) {
+        BitIter it; it.init(mym, P.W, in_flag ? L.occ : nullptr, true);
+        int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * P.n_obs : nullptr;
+        const int gb = P.obs_dim - P.n_obs * 2;
+        const bool cart = P.cartesian != 0;
+        emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+            double gx = 0.0, gy = 0.0;
+            if (cell >= 0) {
+                gx = (double)L.gx[cell] - px; gy = (double)L.gy[cell] - py;      // CPP:285-286, 515-516
+                if (in_flag && P.want_reward) {
+                    double z = sqrt(gx * gx + gy * gy);                          // CPP:524
+                    double psi;                                                  // CPP:1017-1025, delta = 0
+                    if (z < 0.0 * P.d_sen) psi = 1.0;
+                    else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+                    else psi = 0.0;
+                    num0 += psi * gx; num1 += psi * gy; den += psi;              // CPP:537-539
+                }
+            }
+            if (cart) { ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy; }
+            if (sdst) sdst[k] = cell;
+        });
+    }
+
+    // ---- reward: CPP:457-564 ----
+    double reward = 0.0;
+    if (active && P.want_reward) {
+        bool collision = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                                    // CPP:464-496
+            int j = j6[q];
+            if (j >= 0) {
+                double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py;
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (rx * rx + ry * ry < P.T_ravoid) collision = true;    // CPP:487 r_avoid > norm
+            }
+        }
+        bool uniform = false;
+        if (in_flag && n_after > 0) {
+            if (den == 0) den = 1E-8;                                    // CPP:542-544
+            double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;         // CPP:547-548
+            uniform = v0 * v0 + v1 * v1 < P.T_v005;                      // CPP:550-552
+        }
+        if (in_flag && !collision && uniform) reward += 1.0;             // CPP:559-561
+        if (rew_g) rew_g[(size_t)e * n_a + i] = (S)reward;
+    }
+
+    // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
+    if (P.want_stats) {
+        __syncthreads();                                                 // masks no longer needed
+        double *scr = reinterpret_cast<double *>(L.mask);                // 4 doubles per agent (MW >= 8 words)
+        if (active) {
+            scr[(size_t)i * 4 + 0] = reward; scr[(size_t)i * 4 + 1] = sqrt(nn_min);
+            scr[(size_t)i * 4 + 2] = dmin;   scr[(size_t)i * 4 + 3] = in_flag ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (i == 0 && e < P.E) {
+            double rs = 0, rq = 0, ds = 0, inn = 0, ms = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+            for (int a = 0; a < n_a; ++a) {
+                double r = scr[(size_t)a * 4], m = scr[(size_t)a * 4 + 1];
+                rs += r; rq += r * r; ds += scr[(size_t)a * 4 + 2]; inn += scr[(size_t)a * 4 + 3];
+                ms += m; lo = fmin(lo, m); hi = fmax(hi, m);
+            }
+            double mean = ms / n_a, var = 0;
+            for (int a = 0; a < n_a; ++a) { double d = scr[(size_t)a * 4 + 1] - mean; var += d * d; }
+            var /= n_a;
+            int covered = 0;
+            for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
+            double *st = stats_g + (size_t)e * 8;
+            st[0] += rs; st[1] += rq; st[2] += (double)covered / P.n_g_e;
+            st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
+            st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+        }
+    }
+}
+
+// Loads the environment's grid (padded with far-away cells) and state into LDS.
+template <typename S>
+__device__ __forceinline__ void load_env(const DevParams &P, const EnvLds<S> &L, bool env_ok, bool active, int e,
+                                         int i, int n_g, const S *p_g, const S *dp_g, const S *grid_g)
+{
+    for (int c = i; c < P.NGP; c += P.SL) {
+        S x = (S)1e30, y = (S)1e30;
+        if (env_ok && c < n_g) {
+            x = grid_g[(size_t)e * 2 * P.n_g_max + c];
+            y = grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c];
+        }
+        L.gx[c] = x; L.gy[c] = y;
+    }
+    if (active) {
+        const size_t b = (size_t)e * 2 * P.n_a;
+        L.px[i] = p_g[b + i]; L.py[i] = p_g[b + P.n_a + i];
+        L.vx[i] = dp_g[b + i]; L.vy[i] = dp_g[b + P.n_a + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+template <typename S>
+__global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *heading_g, const S *grid_g,
+                          const int *ng_g, const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g,
+                          S *obs_g, S *rew_g, int *sensed_g, int *occup_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    const int n_g = env_ok ? ng_g[e] : 0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
+    __syncthreads();
+    DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0;
+    observe<S>(Q, L, active, e, i, l_cell, heading_g, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+               nullptr, 0);
+}
+
+// ENV:482-661: forces + prior on the old state, integration, observation + reward.
+template <typename S>
+__global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S *grid_g, const int *ng_g,
+                       const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
+                       S *prior_g, int *sensed_g, int *occup_g, double *stats_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    const int n_g = env_ok ? ng_g[e] : 0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
+    __syncthreads();
+
+    double npx = 0, npy = 0, nvx = 0, nvy = 0;
+    int contacts = 0;
+    if (active) {
+        const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
+        // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
+        double fx = 0.0, fy = 0.0;
+        for (int k = 0; k < n_a; ++k) {
+            if (k == i) continue;
+            double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;         // CPP:782-785 (delta = p_k - p_i)
+            double s = dx * dx + dy * dy;                                        // ENV:444 (no wrap for rows >= 1)
+            if (s < P.T_contact) {                                               // ENV:445-446 d - sizes < 0
+                double d = sqrt(s);
+                double gap = fabs(d - P.sizes2);                                 // ENV:447
+                fx += 1.0 * gap * P.k_ball * (-(dx / d));                        // CPP:790-793
+                fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                if (k > i) ++contacts;
+            } else if (P.want_stats && P.periodic && i == 0) {
+                // ENV:442-443: only agent 0's row of the distance matrix is wrapped; it is
+                // never read by the force loop but is counted by WRAP:131-145.
+                double wx = dx, wy = dy; wrap_rel(wx, wy, P.half_w, P.half_h);
+                if (wx * wx + wy * wy < P.T_contact) ++contacts;
+            }
+        }
+        // ---- walls: CPP:822-860, ENV:510-513 ----
+        double wfx = 0.0, wfy = 0.0, dfx = 0.0, dfy = 0.0;
+        if (!P.periodic) {
+            const double r = P.size_a;
+            double d0 = px - r - (-P.half_w);                                    // CPP:841 (boundary_pos[0] = -half_w)
+            double d1 = P.half_h - (py + r);                                     // CPP:842
+            double d2 = P.half_w - (px + r);                                     // CPP:843
+            double d3 = py - r - (-P.half_h);                                    // CPP:844
+            const bool c0 = d0 < 0, c1 = d1 < 0, c2 = d2 < 0, c3 = d3 < 0;       // CPP:849
+            const double a0 = c0 ? fabs(d0) : 0.0, a1 = c1 ? fabs(d1) : 0.0;
+            const double a2 = c2 ? fabs(d2) : 0.0, a3 = c3 ? fabs(d3) : 0.0;
+            wfx = (a0 - a2) * P.k_wall;                                          // ENV:512 row 0: [1,0,-1,0]
+            wfy = (-a1 + a3) * P.k_wall;                                         //         row 1: [0,-1,0,1]
+            dfx = (-(c0 ? vx : 0.0) + -(c2 ? vx : 0.0)) * P.c_wall;              // ENV:513 row 0: [-1,0,-1,0]
+            dfy = (-(c1 ? vy : 0.0) + -(c3 ? vy : 0.0)) * P.c_wall;              //         row 1: [0,-1,0,-1]
+        }
+        // ---- prior on the OLD state with the PREVIOUS neighbour list: ENV:600-619 ----
+        if (P.prior && prior_g) {
+            int nb[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+            double tx, ty;
+            bool inf; int near;
+            if (P.recompute) {
+                double smin; cell_pass<S, false>(P, true, px, py, L.gx, L.gy, i, nullptr, nullptr, nullptr, smin, near);
+                inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
+            } else {
+                inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
+            }
+            if (inf) { tx = px; ty = py; } else { tx = (double)L.gx[near]; ty = (double)L.gy[near]; }  // CPP:896-901
+            double f0, f1;
+            prior_policy<S>(P, px, py, vx, vy, tx, ty, nb, L.px, L.py, L.vx, L.vy, f0, f1);
+            prior_g[(size_t)e * 2 * n_a + i] = (S)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (S)f1;
+        }
+        // ---- integration: ENV:626-647 ----
+        const float sens = (float)P.sens;
+        double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);             // ENV:627,633 (1 * float32)
+        double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        double Fx = ux + fx, Fy = uy + fy;
+        if (!P.periodic) { Fx = Fx + wfx + dfx; Fy = Fy + wfy + dfy; }           // ENV:633
+        nvx = vx + (Fx / P.mass) * P.dt; nvy = vy + (Fy / P.mass) * P.dt;        // ENV:638-641
+        nvx = fmin(fmax(nvx, -P.vel_max), P.vel_max);                            // ENV:642
+        nvy = fmin(fmax(nvy, -P.vel_max), P.vel_max);
+        npx = px + nvx * P.dt; npy = py + nvy * P.dt;                            // ENV:645
+        if (P.periodic) {                                                        // ENV:646-647, 778-781
+            if (npx < -P.half_w) npx += 2 * P.half_w;
+            if (npx > P.half_w) npx -= 2 * P.half_w;
+            if (npy < -P.half_h) npy += 2 * P.half_h;
+            if (npy > P.half_h) npy -= 2 * P.half_h;
+        }
+    }
+    // contact pairs of the environment (upper triangle, WRAP:141-145)
+    int contact_pairs = 0;
+    if (P.want_stats) {
+        __syncthreads();
+        int *cnt = reinterpret_cast<int *>(L.occ);
+        if (i == 0) cnt[0] = 0;
+        __syncthreads();
+        if (active && contacts) atomicAdd(&cnt[0], contacts);
+        __syncthreads();
+        contact_pairs = cnt[0];
+    }
+    __syncthreads();                                                             // all reads of the old state done
+    if (active) {
+        const S a = (S)npx, b = (S)npy, c = (S)nvx, d = (S)nvy;
+        L.px[i] = a; L.py[i] = b; L.vx[i] = c; L.vy[i] = d;
+        const size_t o = (size_t)e * 2 * n_a;
+        p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = d;
+    }
+    __syncthreads();
+    DevParams Q = P; Q.n_g_e = n_g;
+    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+               stats_g, contact_pairs);
+}
+
+// ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset
+// x/y, coin, 2*n_a positions, 2 centre, 2*n_a velocities), then the observation.
+template <typename S>
+__global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
+                        const double *shape_grids, const int *shape_off, const int *shape_ng,
+                        const double *shape_lcell, int *shape_id_g, S *p_g, S *dp_g, S *grid_g, int *ng_g,
+                        double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, int *sensed_g,
+                        int *occup_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    const uint64_t env = (uint64_t)(env0 + e);
+    int n_g = 0; double l_cell = 1.0;
+    if (env_ok) {
+        uint32_t d = 0;
+        const int s = (int)(((uint64_t)draw_u32(seed, env, episode, 0u, d++) * (uint64_t)n_shapes) >> 32);  // ENV:155
+        n_g = shape_ng[s]; l_cell = shape_lcell[s];
+        const double ang = ASM_PI * draw_uniform(seed, env, episode, d++, -1.0, 1.0);                      // ENV:170
+        d += 2;                                                                                            // ENV:177
+        const double ox = draw_uniform(seed, env, episode, d++, -P.half_w + 1, P.half_w - 1);              // ENV:179
+        const double oy = draw_uniform(seed, env, episode, d++, -P.half_h + 1, P.half_h - 1);              // ENV:180
+        const double ca = cos(ang), sa = sin(ang);
+        const double *g = shape_grids + 2 * (size_t)shape_off[s];
+        for (int c = i; c < P.NGP; c += P.SL) {
+            S x = (S)1e30, y = (S)1e30;
+            if (c < n_g) {                                                                                 // ENV:172-173,182
+                double gx = g[2 * c], gy = g[2 * c + 1];
+                x = (S)((ca * gx + sa * gy) + ox); y = (S)((-sa * gx + ca * gy) + oy);
+            }
+            L.gx[c] = x; L.gy[c] = y;
+            if (c < P.n_g_max) {
+                grid_g[(size_t)e * 2 * P.n_g_max + c] = c < n_g ? x : (S)0;
+                grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c] = c < n_g ? y : (S)0;
+            }
+        }
+        const double coin = draw_uniform(seed, env, episode, d++, -1.0, 1.0);                              // ENV:197
+        const uint32_t dpos = d, dctr = d + 2u * (uint32_t)n_a, dvel = dctr + 2u;
+        if (i == 0) { shape_id_g[e] = s; ng_g[e] = n_g; lcell_g[e] = l_cell; }
+        if (active) {
+            double x, y;
+            if (coin > 0) {                                                                                // ENV:198-200
+                x = draw_uniform(seed, env, episode, dpos + (uint32_t)i, -P.half_w, P.half_w);
+                y = draw_uniform(seed, env, episode, dpos + (uint32_t)(n_a + i), -P.half_h, P.half_h);
+            } else {                                                                                       // ENV:202-203
+                const double cx = draw_uniform(seed, env, episode, dctr, -P.half_w + 1, P.half_w - 1);
+                const double cy = draw_uniform(seed, env, episode, dctr + 1u, -P.half_h + 1, P.half_h - 1);
+                x = draw_uniform(seed, env, episode, dpos + (uint32_t)i, -1.0, 1.0) + cx;
+                y = draw_uniform(seed, env, episode, dpos + (uint32_t)(n_a + i), -1.0, 1.0) + cy;
+            }
+            const double u = draw_uniform(seed, env, episode, dvel + (uint32_t)i, -0.5, 0.5);              // ENV:210
+            const double v = draw_uniform(seed, env, episode, dvel + (uint32_t)(n_a + i), -0.5, 0.5);
+            const S a = (S)x, b = (S)y, c = (S)u, dd = (S)v;
+            L.px[i] = a; L.py[i] = b; L.vx[i] = c; L.vy[i] = dd;
+            const size_t o = (size_t)e * 2 * n_a;
+            p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = dd;
+        }
+    } else {
+        for (int c = i; c < P.NGP; c += P.SL) { L.gx[c] = (S)1e30; L.gy[c] = (S)1e30; }
+    }
+    __syncthreads();
+    DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0; Q.want_reward = 0;
+    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, nullptr, sensed_g, occup_g,
+               nullptr, 0);
+}
+
+__global__ void k_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act)
+{
+    const size_t per_env = (size_t)2 * n_a;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)E * per_env) return;
+    const uint64_t env = (uint64_t)(env0 + (int64_t)(idx / per_env));
+    const uint32_t d = (uint32_t)(idx % per_env);
+    const double u = (double)draw_u32(seed, env, step, 1u, d) * (1.0 / 4294967296.0);
+    act[idx] = (float)(-1.0 + 2.0 * u);                                          // ENV:519
+}
+
+__global__ void k_sqrt_f64(const double *in, double *out, int n)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = sqrt(in[k]);
+}
+
+// ---- the three small reference-compatible kernels (double, one environment) ----
+
+// CPP:359-631 on caller-supplied index arrays
+__global__ void k_reward_compat(DevParams P, const double *p, const double *grid, int n_g, const int *nbr,
+                                const int *inflags, const int *sensed, bool c_periodic, bool c_interaction,
+                                bool c_exploration, double *reward)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_a = P.n_a;
+    if (i >= n_a) return;
+    const double px = p[i], py = p[n_a + i];
+    bool collision = false, uniform = false;
+    if (c_interaction) {                                                         // CPP:464-496
+        for (int q = 0; q < P.topo; ++q) {
+            int j = nbr[i * P.topo + q];
+            if (j == -1) continue;
+            double rx = p[j] - px, ry = p[n_a + j] - py;
+            if (c_periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+            if (rx * rx + ry * ry < P.T_ravoid) { collision = true; break; }     // CPP:487
+        }
+    }
+    double r = 0.0;
+    if (c_exploration) {                                                         // CPP:499-564
+        if (inflags[i] == 1) {
+            double num0 = 0, num1 = 0, den = 0; bool any = false;
+            for (int k = 0; k < P.n_obs; ++k) {
+                int c = sensed[i * P.n_obs + k];
+                if (c == -1) continue;
+                any = true;
+                double gx = grid[c] - px, gy = grid[n_g + c] - py;
+                double z = sqrt(gx * gx + gy * gy), psi;
+                if (z < 0.0 * P.d_sen) psi = 1.0;
+                else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+                else psi = 0.0;
+                num0 += psi * gx; num1 += psi * gy; den += psi;
+            }
+            if (any) {
+                if (den == 0) den = 1E-8;
+                double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;
+                uniform = v0 * v0 + v1 * v1 < P.T_v005;
+            }
+        }
+        if (inflags[i] == 1 && !collision && uniform) r += 1.0;
+    }
+    reward[i] = r;
+}
+
+// CPP:740-820 on caller-supplied distance / contact matrices
+__global__ void k_sf_b2b_compat(const double *p, const double *d_edge, const bool *collide, const double *d_center,
+                                int n_a, double k_ball, bool periodic, double hw, double hh, double *sf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_a) return;
+    double sx = 0.0, sy = 0.0;
+    for (int k = 0; k < n_a; ++k) {
+        if (k == i) { sx += 0.0; sy += 0.0; continue; }
+        const int a = k < i ? i : k, b = k < i ? k : i;                          // entry (a, b), b < a
+        double dx = p[b] - p[a], dy = p[n_a + b] - p[n_a + a];                   // CPP:782-785
+        if (periodic) wrap_rel(dx, dy, hw, hh);
+        const double dc = d_center[(size_t)a * n_a + b];
+        const double m = (double)collide[(size_t)a * n_a + b] * d_edge[(size_t)a * n_a + b] * k_ball;
+        double ex = m * (-(dx / dc)), ey = m * (-(dy / dc));                     // CPP:790-793
+        if (k > i) { ex = -ex; ey = -ey; }                                       // CPP:795-796
+        sx += ex; sy += ey;                                                      // CPP:804-812
+    }
+    sf[i] = sx; sf[n_a + i] = sy;
+}
+
+// CPP:822-860
+__global__ void k_dist_b2w_compat(const double *p, const double *r, int n_a, double b0, double b1, double b2,
+                                  double b3, double *d_b2w, bool *coll)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_a) return;
+    double d[4];
+    d[0] = p[i] - r[i] - b0; d[1] = b1 - (p[n_a + i] + r[i]);
+    d[2] = b2 - (p[i] + r[i]); d[3] = p[n_a + i] - r[i] - b3;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { coll[w * n_a + i] = d[w] < 0; d_b2w[w * n_a + i] = fabs(d[w]); }
+}
+
+// CPP:1066-1123: own nearest-cell search, then robotPolicy
+__global__ void k_prior_compat(DevParams P, const double *p, const double *dp, const double *grid, int n_g,
+                               const int *nbr, double l_cell, double *a_prior)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_a = P.n_a;
+    if (i >= n_a) return;
+    const double px = p[i], py = p[n_a + i];
+    double smin = __builtin_inf(); int imin = 0;
+    for (int c = 0; c < n_g; ++c) {
+        double rx = grid[c] - px, ry = grid[n_g + c] - py;
+        double s = rx * rx + ry * ry;
+        if (s < smin) { smin = s; imin = c; }
+    }
+    const bool inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
+    double tx = inf ? px : grid[imin], ty = inf ? py : grid[n_g + imin];
+    int nb[6];
+    for (int q = 0; q < 6; ++q) nb[q] = q < P.topo ? nbr[i * P.topo + q] : -1;
+    double f0, f1;
+    prior_policy<double>(P, px, py, dp[i], dp[n_a + i], tx, ty, nb, p, p + n_a, dp, dp + n_a, f0, f1);
+    a_prior[i] = f0; a_prior[n_a + i] = f1;
+}
+
+// ---------------------------------------------------------------------------------
+// launchers
+#define LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return (int)_e; } while (0)
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <typename S>
+int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading, const S *grid, const int *n_g,
+                   const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, int *sensed,
+                   int *occupied, hipStream_t st)
+{
+    if (int rc = set_lds(k_observe<S>, P.lds_block_bytes)) return rc;
+    hipLaunchKernelGGL(k_observe<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, p, dp, heading, grid, n_g,
+                       l_cell, nbr, inflags, nearest, obs, rew, sensed, occupied);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename S>
+int launch_step(const DevParams &P, S *p, S *dp, const float *act, const S *grid, const int *n_g,
+                const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
+                int *occupied, double *stats, hipStream_t st)
+{
+    if (int rc = set_lds(k_step<S>, P.lds_block_bytes)) return rc;
+    hipLaunchKernelGGL(k_step<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, p, dp, act, grid, n_g, l_cell,
+                       nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename S>
+int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
+                 const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,
+                 int *shape_id, S *p, S *dp, S *grid, int *n_g, double *l_cell, int *nbr, int *inflags, int *nearest,
+                 S *obs, int *sensed, int *occupied, hipStream_t st)
+{
+    if (int rc = set_lds(k_reset<S>, P.lds_block_bytes)) return rc;
+    hipLaunchKernelGGL(k_reset<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, seed, episode, env0,
+                       n_shapes, shape_grids, shape_off, shape_ng, shape_lcell, shape_id, p, dp, grid, n_g, l_cell, nbr,
+                       inflags, nearest, obs, sensed, occupied);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template int launch_observe<float>(const DevParams &, const float *, const float *, const float *, const float *,
+                                   const int *, const double *, int *, int *, int *, float *, float *, int *, int *,
+                                   hipStream_t);
+template int launch_observe<double>(const DevParams &, const double *, const double *, const double *, const double *,
+                                    const int *, const double *, int *, int *, int *, double *, double *, int *, int *,
+                                    hipStream_t);
+template int launch_step<float>(const DevParams &, float *, float *, const float *, const float *, const int *,
+                                const double *, int *, int *, int *, float *, float *, float *, int *, int *, double *,
+                                hipStream_t);
+template int launch_reset<float>(const DevParams &, uint64_t, uint32_t, int64_t, int, const double *, const int *,
+                                 const int *, const double *, int *, float *, float *, float *, int *, double *, int *,
+                                 int *, int *, float *, int *, int *, hipStream_t);
+
+int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st)
+{
+    const size_t n = (size_t)E * 2 * n_a;
+    hipLaunchKernelGGL(k_random_actions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, step, env0, E, n_a, act);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sqrt(const double *in, double *out, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sqrt_f64, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_reward_compat(const DevParams &P, const double *p, const double *grid, int n_g, const int *nbr,
+                         const int *inflags, const int *sensed, bool c0, bool c3, bool c4, double *reward, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reward_compat, dim3((P.n_a + 63) / 64), dim3(64), 0, st, P, p, grid, n_g, nbr, inflags, sensed,
+                       c0, c3, c4, reward);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sf_b2b_compat(const double *p, const double *d_edge, const bool *collide, const double *d_center, int n_a,
+                         double k_ball, bool periodic, double hw, double hh, double *sf, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sf_b2b_compat, dim3((n_a + 63) / 64), dim3(64), 0, st, p, d_edge, collide, d_center, n_a,
+                       k_ball, periodic, hw, hh, sf);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_dist_b2w_compat(const double *p, const double *r, int n_a, const double *bpos_host, double *d_b2w,
+                           bool *coll, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dist_b2w_compat, dim3((n_a + 63) / 64), dim3(64), 0, st, p, r, n_a, bpos_host[0], bpos_host[1],
+                       bpos_host[2], bpos_host[3], d_b2w, coll);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_prior_compat(const DevParams &P, const double *p, const double *dp, const double *grid, int n_g,
+                        const int *nbr, double l_cell, double *a_prior, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_prior_compat, dim3((P.n_a + 63) / 64), dim3(64), 0, st, P, p, dp, grid, n_g, nbr, l_cell,
+                       a_prior);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace asmenv

@@ -1,0 +1,262 @@
+"""GPU parity tests of the batched HIP path (C ABI group B of include/marl_amd_env.h)
+against the CPU oracle and the golden vectors.  Run with -m gpu on an MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROLLOUTS = sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def _env_from_golden(torch, z, E=1, keep_indices=True):
+    from marl_amd.batched import BatchedAssemblyEnv
+    grid = z["grid"]; n_g = grid.shape[1]
+    env = BatchedAssemblyEnv(E, int(z["n_a"]), r_avoid=float(z["r_avoid"]), is_boundary=bool(z["is_boundary"]),
+                             is_con_self_state=bool(z["is_con_self_state"]), d_sen=float(z["d_sen"]),
+                             keep_indices=keep_indices, n_g_max=(n_g + 31) // 32 * 32)
+    g = np.zeros((E, 2, env.n_g_max), np.float32); g[:, :, :n_g] = grid.astype(np.float32)
+    env.grid_center.copy_(torch.from_numpy(g)); env.n_g.fill_(n_g); env.l_cell.fill_(float(z["l_cell"]))
+    return env
+
+
+def test_device_sqrt_f64_is_correctly_rounded(torch_cuda):
+    """The kernels use device sqrt(double) for the in-shape test and the reward weights."""
+    torch = torch_cuda
+    import ctypes as C
+    from marl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(0, 30, 500000), rng.uniform(0, 1e-3, 200000), 10.0 ** rng.uniform(-12, 3, 300000),
+                        np.array([0.0, 0.16, 0.4 ** 2, 0.0169, 0.0049])])
+    xin = torch.from_numpy(x).cuda(); out = torch.empty_like(xin)
+    _lib.check(lib.asm_debug_sqrt_f64(C.c_void_p(xin.data_ptr()), C.c_void_p(out.data_ptr()), x.size, None), "sqrt")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.sqrt(x))
+
+
+@pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p)[8:-4] for p in ROLLOUTS])
+def test_golden_states_observe_and_step(torch_cuda, path):
+    """Every recorded reference state, rounded to the fp32 state the device holds:
+    observation + teacher-forced step against the oracle (indices exact)."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    z = np.load(path)
+    T = z["act"].shape[0]
+    env = _env_from_golden(torch, z, E=T)
+    cfg = cfg_from_env(env)
+    # environment t of the batch = the recorded state before step t
+    p = np.concatenate([z["p0"][None], z["p"][:-1]]).astype(np.float32)
+    dp = np.concatenate([z["dp0"][None], z["dp"][:-1]]).astype(np.float32)
+    env.p.copy_(torch.from_numpy(p)); env.dp.copy_(torch.from_numpy(dp))
+    env.observe(want_reward=True)
+    o = check_observation(env, cfg, True, "golden observe")
+    # fp32 rounding of the state may flip a borderline decision w.r.t. the recorded
+    # double-precision run, so the direct comparison is statistical, not exact
+    nbr_ref = np.concatenate([z["nbr0"][None], z["nbr"][:-1]])
+    assert (o["nbr"] == nbr_ref).mean() > 0.999
+    teacher_forced_step(env, cfg, z["act"].astype(np.float32), "golden step")
+    # sanity only: the recorded run started from the double-precision state, the device
+    # from its float32 rounding, and a contact spring (k_ball = 30) amplifies that input
+    # difference; the contract check is the teacher-forced one above
+    np.testing.assert_allclose(env.p.cpu().numpy(), z["p"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(env.dp.cpu().numpy(), z["dp"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_a,E,steps,boundary", [(30, 64, 25, True), (30, 33, 12, False), (10, 17, 10, True),
+                                                   (7, 9, 6, True), (33, 5, 6, True), (64, 6, 6, True),
+                                                   (100, 3, 4, True), (1, 4, 4, True)])
+def test_random_rollout_teacher_forced(torch_cuda, n_a, E, steps, boundary):
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    env = BatchedAssemblyEnv(E, n_a, seed=100 + n_a, is_boundary=boundary, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    check_observation(env, cfg, False, "reset")
+    rng = np.random.default_rng(n_a)
+    tot = 0.0
+    for t in range(steps):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        o, _ = teacher_forced_step(env, cfg, act, f"step {t}")
+        tot += o["rew"].sum()
+    assert np.isfinite(tot)
+
+
+def test_converged_regime_teacher_forced(torch_cuda):
+    """Agents packed inside the shape: sensed lists above 80, occupied cells, contacts,
+    rewards — the regime random actions rarely reach."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E, n_a = 48, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=5, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(3)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy()
+    p = np.zeros((E, 2, n_a), np.float32)
+    for e in range(E):
+        idx = rng.choice(n_g[e], n_a, replace=False)
+        p[e] = grid[e][:, idx] + rng.normal(0, 0.03 if e % 2 else 0.004, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.dp.copy_(torch.from_numpy(rng.uniform(-0.2, 0.2, (E, 2, n_a)).astype(np.float32)))
+    env.observe(want_reward=True)
+    o = check_observation(env, cfg, True, "packed observe")
+    assert (o["sensed"] >= 0).sum(-1).max() == 80 and (o["occupied"] >= 0).sum(-1).max() > 20
+    assert o["in_flags"].mean() > 0.8
+    rew = 0; cont = 0
+    for t in range(8):
+        o, contacts = teacher_forced_step(env, cfg, rng.uniform(-0.3, 0.3, (E, 2, n_a)).astype(np.float32), f"packed {t}")
+        rew += o["rew"].sum(); cont += contacts.sum()
+    assert rew > 0 and cont > 0
+
+
+def test_large_sensing_radius_subsamples_both_lists(torch_cuda):
+    """d_sen = 1.2: occupied > 200 and sensed > 80, both subsampled (CPP:223-233, 243-261)."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, check_observation
+    z = np.load(os.path.join(GOLDEN, "fn_occ200.npz"))
+    from marl_amd.batched import BatchedAssemblyEnv
+    n_a = z["p"].shape[1]; n_g = z["grid"].shape[1]
+    env = BatchedAssemblyEnv(2, n_a, r_avoid=float(z["r_avoid"]), d_sen=float(z["d_sen"]), keep_indices=True, n_g_max=544)
+    g = np.zeros((2, 2, 544), np.float32); g[:, :, :n_g] = z["grid"].astype(np.float32)
+    env.grid_center.copy_(torch.from_numpy(g)); env.n_g.fill_(n_g); env.l_cell.fill_(float(z["l_cell"]))
+    env.p.copy_(torch.from_numpy(np.stack([z["p"], z["p"] + 0.01]).astype(np.float32)))
+    env.dp.copy_(torch.from_numpy(np.stack([z["dp"], z["dp"]]).astype(np.float32)))
+    env.observe(want_reward=True)
+    o = check_observation(env, cfg_from_env(env), True, "occ200")
+    assert (o["occupied"] >= 0).sum(-1).max() == 200 and (o["sensed"] >= 0).sum(-1).max() == 80
+
+
+def test_reset_matches_oracle_and_shards(torch_cuda):
+    torch = torch_cuda
+    import oracle_lib as ol
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import ulp_diff_f32
+    E, n_a = 96, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=226)
+    env.reset(episode=3)
+    sid, p, dp, grid, n_g, l_cell = ol.batch_reset(226, 3, 0, E, n_a, env.grid_center_origins, env.l_cells, env.n_g_max)
+    assert np.array_equal(env.shape_id.cpu().numpy(), sid) and np.array_equal(env.n_g.cpu().numpy(), n_g)
+    assert np.array_equal(env.l_cell.cpu().numpy(), l_cell)
+    assert np.array_equal(env.p.cpu().numpy(), p.astype(np.float32))          # pure integer/fp64 arithmetic: exact
+    assert np.array_equal(env.dp.cpu().numpy(), dp.astype(np.float32))
+    # the grid goes through device cos/sin, which may differ from libm in the last bits
+    assert ulp_diff_f32(env.grid_center.cpu().numpy(), grid).max() <= 1
+    # the same global ids from a different shard give the same environments
+    env2 = BatchedAssemblyEnv(40, n_a, seed=226, env_id_offset=56)
+    env2.reset(episode=3)
+    for name in ("p", "dp", "grid_center", "obs", "neighbor_index", "in_flags"):
+        assert torch.equal(getattr(env2, name), getattr(env, name)[56:]), name
+
+
+def test_full_size_properties(torch_cuda):
+    """4096 x 30 (the benchmark configuration): properties that need no oracle pass
+    over every environment, plus the oracle on a sample."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env
+    import oracle_lib as ol
+    E, n_a = 4096, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=226, keep_indices=True)
+    env.reset()
+    perm = torch.randperm(E, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    twin = BatchedAssemblyEnv(E, n_a, seed=226, keep_indices=True)
+    for name in ("p", "dp", "grid_center", "n_g", "l_cell"):
+        getattr(twin, name).copy_(getattr(env, name)[perm])
+    twin.observe()
+    rsum = 0.0
+    for t in range(20):
+        a = env.random_actions()
+        obs, rew, done, _, prior = env.step(a)
+        o2, r2, _, _, p2 = twin.step(a[perm].contiguous())
+        # environments are independent: a permuted batch gives the permuted results, bit for bit
+        assert torch.equal(o2, obs[perm]) and torch.equal(r2, rew[perm]) and torch.equal(p2, prior[perm])
+        assert torch.equal(twin.neighbor_index, env.neighbor_index[perm]) and torch.equal(twin.sensed_index, env.sensed_index[perm])
+        rsum += float(rew.sum())
+        assert torch.isfinite(obs).all() and float(env.p.abs().max()) <= 2.4 + 0.1 and float(env.dp.abs().max()) <= 0.8
+        assert set(torch.unique(rew).tolist()) <= {0.0, 1.0}
+        # sensed lists are ascending and -1 padded at the tail only
+        s = env.sensed_index
+        valid = s >= 0
+        assert bool((valid[..., 1:] <= valid[..., :-1]).all())
+        assert bool(((s[..., 1:] > s[..., :-1]) | ~valid[..., 1:]).all())
+    st = env.episode_stats().cpu().numpy()
+    assert st[0] == pytest.approx(rsum) and st[6] == 20 * E
+    # oracle on a sample of environments of the final state
+    cfg = cfg_from_env(env)
+    idx = np.arange(0, E, 97)
+    from gpu_util import oracle_observe_batch, assert_close
+    o = oracle_observe_batch(cfg, env.p[idx].cpu().numpy(), env.dp[idx].cpu().numpy(), env.grid_center[idx].cpu().numpy(),
+                             env.n_g[idx].cpu().numpy(), env.l_cell[idx].cpu().numpy())
+    assert np.array_equal(env.neighbor_index[idx].cpu().numpy(), o["nbr"])
+    assert np.array_equal(env.sensed_index[idx].cpu().numpy(), o["sensed"])
+    assert np.array_equal(env.reward[idx].cpu().numpy().astype(np.float64), o["rew"])
+    assert_close(env.obs[idx].cpu().numpy(), o["obs"], "obs sample")
+
+
+def test_stats_match_wrapper_metrics(torch_cuda):
+    """Per-step statistics against the oracle's restatement of the wrapper metrics."""
+    torch = torch_cuda
+    import oracle_lib as ol
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, oracle_dynamics_batch
+    E, n_a = 24, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=9)
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(0)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy(); l_cell = env.l_cell.cpu().numpy()
+    p = np.zeros((E, 2, n_a), np.float32)
+    for e in range(E):
+        p[e] = grid[e][:, rng.choice(n_g[e], n_a, replace=False)] + rng.normal(0, 0.02, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.observe()
+    want = np.zeros((E, 8))
+    for t in range(3):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        p0 = env.p.cpu().numpy(); dp0 = env.dp.cpu().numpy(); nbr0 = env.neighbor_index.cpu().numpy()
+        _, _, _, contacts = oracle_dynamics_batch(cfg, p0, dp0, act, grid, n_g, l_cell, nbr0)
+        obs, rew, *_ = env.step(torch.from_numpy(act).cuda())
+        p1 = env.p.cpu().numpy().astype(np.float64); r = rew.cpu().numpy().astype(np.float64)
+        for e in range(E):
+            g = np.ascontiguousarray(grid[e][:, :n_g[e]], dtype=np.float64)
+            m = ol.metrics(np.ascontiguousarray(p1[e]), g, env.r_avoid)
+            want[e] += [r[e].sum(), (r[e] ** 2).sum(), m["coverage_rate"], m["distribution_uniformity"], contacts[e],
+                        m["avg_distance_to_target"], 1.0, env.in_flags[e].sum().item()]
+    np.testing.assert_allclose(env.stats.cpu().numpy(), want, rtol=1e-9, atol=1e-12)
+
+
+def test_big_swarm_one_step(torch_cuda):
+    """256-agent and 1024-agent environments (one workgroup per environment)."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    for n_a, E in ((256, 3), (1024, 2)):
+        env = BatchedAssemblyEnv(E, n_a, seed=n_a, keep_indices=True)
+        cfg = cfg_from_env(env)
+        env.reset()
+        check_observation(env, cfg, False, f"reset {n_a}")
+        rng = np.random.default_rng(n_a)
+        for t in range(2):
+            teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"n_a {n_a} step {t}")
+
+
+def test_argument_errors(torch_cuda):
+    from marl_amd.batched import BatchedAssemblyEnv
+    with pytest.raises(RuntimeError, match="n_a"):
+        BatchedAssemblyEnv(2, 2000).reset()
+    env = BatchedAssemblyEnv(2, 30)
+    env.reset()
+    import torch
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(2, 2, 29, device="cuda"))

@@ -1,0 +1,83 @@
+"""The five reference-named entry points of libAssemblyEnv.so (host double pointers,
+computed on the GPU in double) against the CPU oracle and the golden vectors:
+bit-exact on every index and on every value that involves no transcendental."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROLLOUTS = sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
+BPOS = np.array([-2.4, 2.4, 2.4, -2.4])
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from marl_amd import _lib
+    lib = _lib.load()
+    assert lib.asm_device_count() >= 1, lib.asm_last_error()
+    return ol.FiveFns(lib, False)
+
+
+@pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p)[8:-4] for p in ROLLOUTS])
+def test_five_symbols_on_golden_states(hip, path):
+    z = np.load(path)
+    orc = ol.oracle_fns()
+    grid = np.ascontiguousarray(z["grid"]); l_cell = float(z["l_cell"]); d_sen = float(z["d_sen"]); r_avoid = float(z["r_avoid"])
+    periodic = not bool(z["is_boundary"]); con_self = bool(z["is_con_self_state"])
+    T = z["act"].shape[0]
+    for t in range(0, T, max(1, T // 4)):
+        p = np.ascontiguousarray(z["p"][t]); dp = np.ascontiguousarray(z["dp"][t]); heading = np.zeros_like(p)
+        cond = (periodic, True, con_self, False)
+        obs, nbr, inf, sen, occ = hip.get_observation(p, dp, heading, BPOS, grid, d_sen, r_avoid, l_cell, cond=cond)
+        # straight against what the reference produced for this state
+        assert np.array_equal(obs, z["obs"][t]) and np.array_equal(nbr, z["nbr"][t])
+        assert np.array_equal(inf, z["in_flags"][t]) and np.array_equal(sen, z["sensed"][t])
+        assert np.array_equal(occ, z["occupied"][t])
+        rew = hip.get_reward(p, dp, heading, dp, BPOS, grid, nbr, inf, sen, occ, d_sen, r_avoid, l_cell,
+                             cond=(periodic, True, True, True, True))
+        assert np.array_equal(rew, z["rew"][t])
+        # dynamics pieces on the state BEFORE step t
+        p0 = np.ascontiguousarray(z["p"][t - 1] if t else z["p0"]); dp0 = np.ascontiguousarray(z["dp"][t - 1] if t else z["dp0"])
+        nbr0 = np.ascontiguousarray(z["nbr"][t - 1] if t else z["nbr0"])
+        dc, de, co = ol.get_dist_b2b(p0, periodic=periodic)
+        sf_h = hip.sf_b2b_all(p0, de, co, BPOS, dc, 30.0, periodic)
+        assert np.array_equal(sf_h, orc.sf_b2b_all(p0, de, co, BPOS, dc, 30.0, periodic))
+        size = np.full(p0.shape[1], 0.035)
+        for a, b in zip(hip.get_dist_b2w(p0, size, BPOS), orc.get_dist_b2w(p0, size, BPOS)):
+            assert np.array_equal(a, b)
+        pr = hip.prior(p0, dp0, grid, nbr0, d_sen, r_avoid, l_cell)
+        assert np.array_equal(pr, z["prior"][t])
+
+
+def test_non_cartesian_and_big_radius(hip):
+    orc = ol.oracle_fns()
+    z = np.load(os.path.join(GOLDEN, "fn_occ200.npz"))
+    p = np.ascontiguousarray(z["p"]); dp = np.ascontiguousarray(z["dp"]); grid = np.ascontiguousarray(z["grid"])
+    heading = np.random.default_rng(0).uniform(-1, 1, p.shape)
+    d_sen, r_avoid, l_cell = float(z["d_sen"]), float(z["r_avoid"]), float(z["l_cell"])
+    got = hip.get_observation(p, dp, heading, BPOS, grid, d_sen, r_avoid, l_cell)
+    for name, g in zip(("obs", "nbr", "in_flags", "sensed", "occupied"), got):
+        assert np.array_equal(g, z[name]), name
+    for cond in [(False, False, True, False), (True, False, False, False), (True, True, True, False)]:
+        a = hip.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell, cond=cond)
+        b = orc.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell, cond=cond)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_walls_and_contacts_crowded_corner(hip):
+    """60 agents pushed into a wall corner: many contacts and wall hits."""
+    orc = ol.oracle_fns()
+    rng = np.random.default_rng(5)
+    p = np.ascontiguousarray(np.stack([rng.uniform(2.0, 2.45, 60), rng.uniform(-2.45, -2.0, 60)]))
+    dc, de, co = ol.get_dist_b2b(p)
+    assert co.sum() > 20
+    assert np.array_equal(hip.sf_b2b_all(p, de, co, BPOS, dc), orc.sf_b2b_all(p, de, co, BPOS, dc))
+    size = np.full(60, 0.035)
+    a = hip.get_dist_b2w(p, size, BPOS); b = orc.get_dist_b2w(p, size, BPOS)
+    assert a[1].sum() > 5 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
