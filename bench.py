@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched assembly-environment step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E] [--agents n_a]
+
+One "step" = one pass of the hot path (assembly.py:482-661 for every environment of
+the batch: contact/wall forces, prior, integration, observation, reward) over
+E environments x n_a agents per GPU, actions already resident in HBM.
+N > 1: launched by torch.distributed.run, one rank per GPU; environments are sharded
+by global id, no data-path collective; one RCCL all-reduce of the 8-value
+episode-statistics vector per 200-step episode.
+
+Rank 0 prints ONE JSON line: whole-job agent-steps/s, the roofline of the dominant
+kernel (k_step) from HIP-event timing, and at N = 1 the CPU baseline (the compiled
+reference AssemblyEnv.cpp if oracle/_ref travels with the tree, else our C port)
+timed on the host cores in the same run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+EPISODE_LENGTH = 200           # marl_llm/cfg/assembly_cfg.py:192
+
+
+def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
+    """Algorithmic HBM bytes per agent-step with fp32 state and a fused step:
+    reads p,dp 16 + action 8 + previous neighbour list 24 + grid share 8*n_g/n_a;
+    writes p,dp 16 + obs 4*192 + reward 4 + a_prior 8 + neighbour list 24 + in_flag 4."""
+    return 872.0 + 8.0 * n_g_mean / n_a
+
+
+def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 12.0):
+    """The CPU path on a bounded sample of the same workload, all host threads we may use."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import oracle_lib as ol
+    from marl_amd.shapes import load_shapes
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    kind = "port"
+    if os.path.isfile(ol.REF_SO):
+        try:
+            ol.bind(ol.REF_SO)
+            kind = "reference"
+        except Exception:
+            ol.bind(None)
+    l_cells, grids = load_shapes()
+    cfg = ol.make_cfg(n_a=n_a, r_avoid=r_avoid)
+    n_g_max = (max(g.shape[0] for g in grids) + 31) // 32 * 32
+    rng = np.random.default_rng(0)
+
+    def run(E, T):
+        sid, p, dp, grid, n_g, l_cell = ol.batch_reset(226, 0, 0, E, n_a, grids, l_cells, n_g_max)
+        act = rng.uniform(-1, 1, (T, E, 2, n_a)).astype(np.float32)
+        t0 = time.perf_counter()
+        ol.run_envs(cfg, T, threads, p, dp, act, grid, n_g, l_cell)
+        return time.perf_counter() - t0
+
+    # calibrate on a small sample, then size the sample for ~target_seconds
+    E0, T0 = threads * 2, 20
+    dt = run(E0, T0)
+    per_env_step = dt * threads / (E0 * T0)                  # thread-seconds per env-step
+    T = EPISODE_LENGTH
+    E = max(threads, int(target_seconds * threads / (per_env_step * T)) // threads * threads)
+    dt = run(E, T)
+    ol.bind(None)
+    return {"value": E * T * n_a / dt, "unit": "agent-steps/s", "cores": threads, "kind": kind,
+            "sample": f"{E} envs x {n_a} agents x {T} steps, {dt:.1f} s wall on {threads} threads "
+                      f"({'compiled reference AssemblyEnv.cpp' if kind == 'reference' else 'C port of the reference'} "
+                      f"driven by the C step loop of oracle/asm_oracle.c)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--agents", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-indices", action="store_true", help="also materialise sensed/occupied index lists")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from marl_amd.batched import BatchedAssemblyEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    E, n_a, K, W = args.envs_per_gpu, args.agents, args.steps, args.warmup
+    env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=rank * E, keep_indices=args.keep_indices)
+    env.reset(episode=0)
+    ring = min(max(K, 1), 64)
+    actions = torch.empty(ring, E, 2, n_a, dtype=torch.float32, device=device)
+    for k in range(ring):
+        env.random_actions(out=actions[k], step=k)
+    n_g_mean = float(env.n_g.double().mean())
+    totals = torch.zeros(8, dtype=torch.float64, device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(n, t0=0):
+        for t in range(t0, t0 + n):
+            env.step(actions[t % ring])
+            if (t + 1) % EPISODE_LENGTH == 0:               # end of episode (TRAIN:99,107,177-197)
+                s = env.episode_stats()
+                if world > 1:
+                    dist.all_reduce(s)                       # RCCL SUM of 8 doubles over xGMI
+                totals.add_(s)
+                env.reset()
+
+    # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
+    # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
+    run_steps(W)
+    s0 = env.episode_stats()
+    if world > 1:
+        dist.all_reduce(s0)
+    totals.add_(s0).zero_()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run_steps(K, W)
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax)
+
+    if rank == 0:
+        agent_steps = world * E * n_a * K
+        value = agent_steps / wall
+        b_alg = b_alg_per_agent_step(n_a, n_g_mean)
+        resets = sum(1 for t in range(W, W + K) if (t + 1) % EPISODE_LENGTH == 0)
+        kern_ms = ev_ms / K                                   # k_step launches back to back on one stream
+        achieved = E * n_a * b_alg / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "agent-steps/sec (whole node) for batched 30-agent assembly envs at 1/2/4/8 GPUs",
+            "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{E} parallel assembly envs x {n_a} agents per GPU, random U(-1,1) actions "
+                                   f"(configs[1] of BASELINE.json), 7 reference shapes, walls on, llm_rl prior on",
+                       "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
+                       "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,
+                       "state": "float32 in HBM; decisions evaluated in float64",
+                       "parallelism": f"env-sharded x{world}, RCCL all-reduce of 8 doubles per episode"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step<float>", "avg_launch_ms": kern_ms,
+                         "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": E * n_a},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n_a, env.r_avoid)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
