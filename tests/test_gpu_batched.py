@@ -184,7 +184,7 @@ def test_full_size_properties(torch_cuda):
         assert torch.equal(o2, obs[perm]) and torch.equal(r2, rew[perm]) and torch.equal(p2, prior[perm])
         assert torch.equal(twin.neighbor_index, env.neighbor_index[perm]) and torch.equal(twin.sensed_index, env.sensed_index[perm])
         rsum += float(rew.sum())
-        assert torch.isfinite(obs).all() and float(env.p.abs().max()) <= 2.4 + 0.1 and float(env.dp.abs().max()) <= 0.8
+        assert torch.isfinite(obs).all() and float(env.p.abs().max()) <= 2.4 + 0.1 and float(env.dp.abs().max()) <= float(np.float32(0.8))
         assert set(torch.unique(rew).tolist()) <= {0.0, 1.0}
         # sensed lists are ascending and -1 padded at the tail only
         s = env.sensed_index

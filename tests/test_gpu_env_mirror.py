@@ -1,0 +1,56 @@
+"""The reference-shaped single environment (marl_amd.gym) driven through the recorded
+reference rollouts: every call goes to the GPU through the five C symbols, and every
+output must equal what the reference produced — bit for bit, in double."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROLLOUTS = sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
+
+
+def _make(z):
+    import marl_amd.gym as gym
+    from marl_amd.gym.wrappers import AssemblySwarmWrapper
+    from marl_amd.cfg import AssemblyArgs
+    args = AssemblyArgs(n_a=int(z["n_a"]), is_boundary=bool(z["is_boundary"]), is_con_self_state=bool(z["is_con_self_state"]))
+    env = AssemblySwarmWrapper(gym.make("AssemblySwarm-v0").unwrapped, args)
+    np.random.seed(0)
+    env.reset()
+    e = env.env
+    assert e.r_avoid == float(z["r_avoid"])                     # ENV:122 from the packaged grids
+    e.grid_center = np.ascontiguousarray(z["grid"]); e.n_g = e.grid_center.shape[1]; e.l_cell = float(z["l_cell"])
+    e.p = z["p0"].copy(); e.dp = z["dp0"].copy()
+    return env
+
+
+@pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p)[8:-4] for p in ROLLOUTS])
+def test_recorded_rollout_bit_exact(path):
+    z = np.load(path)
+    env = _make(z); e = env.env
+    obs0 = e._get_obs()
+    assert np.array_equal(obs0, z["obs0"]) and np.array_equal(e.neighbor_index, z["nbr0"])
+    assert env.num_agents == int(z["n_a"]) and env.agent_types == ["agent"]
+    assert env.observation_space.shape == z["obs0"].shape and env.action_space.shape == (2, int(z["n_a"]))
+    for t in range(z["act"].shape[0]):
+        obs, rew, done, info, prior = env.step(z["act"][t])
+        assert done.shape == (1, e.n_a) and not done.any() and info.shape == (3, 1)
+        for name, got in [("obs", obs), ("rew", rew), ("prior", prior), ("p", e.p), ("dp", e.dp), ("nbr", e.neighbor_index),
+                          ("in_flags", e.in_flags), ("sensed", e.sensed_index), ("occupied", e.occupied_index),
+                          ("collide", e.is_collide_b2b)]:
+            assert np.array_equal(got, z[name][t]), f"{name} differs at step {t}"
+    assert env.count_collisions() == int(np.triu(z["collide"][-1], 1).sum())
+    assert 0.0 <= env.coverage_rate() <= 1.0 and env.average_distance_to_target() >= 0.0
+
+
+def test_reset_draw_order_matches_reference_ranges():
+    z = np.load(ROLLOUTS[0])
+    env = _make(z)
+    np.random.seed(226)
+    obs = env.reset()
+    e = env.env
+    assert obs.shape == (192, e.n_a) and e.d_sen == 0.4 and np.array_equal(e.boundary_pos, [-2.4, 2.4, 2.4, -2.4])
+    assert np.abs(e.p).max() <= 2.4 and np.abs(e.dp).max() <= 0.5 and e.n_g in (497, 487, 534, 516, 510, 502, 536)

@@ -1,0 +1,114 @@
+"""CPU-side checks: the C-ABI library exists, loads and exports every declared
+symbol (no compute calls here), header and binding agree, the gym-shaped shim and the
+shape pipeline behave like the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from marl_amd import _lib
+    assert os.path.isfile(_lib.SO_PATH), "build with `make -C marl_amd/csrc`"
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    header = open(os.path.join(REPO, "include", "marl_amd_env.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(_get_observation|_get_reward|_sf_b2b_all|_get_dist_b2w|calculateActionPrior|asm_\w+)\s*\(", header))
+    declared.discard("asm_params")
+    assert declared == set(_lib.EXPORTS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    lib.asm_abi_version.restype = ctypes.c_int
+    assert lib.asm_abi_version() == _lib.ABI_VERSION        # pure host call
+
+
+def test_params_struct_matches_header_defaults():
+    from marl_amd import _lib
+    p = _lib.default_params(30, 544, 0.26)
+    assert (p.n_a, p.n_g_max, p.topo_nei_max, p.num_obs_grid_max, p.num_occupied_grid_max) == (30, 544, 6, 80, 200)
+    assert (p.size_a, p.d_sen, p.r_avoid, p.vel_max, p.k_ball, p.k_wall, p.c_wall, p.dt) == (0.035, 0.4, 0.26, 0.8, 30, 100, 5, 0.1)
+    assert _lib.load().asm_obs_dim(ctypes.byref(p)) == 192   # ENV:806
+    p.is_con_self_state = 0
+    assert _lib.load().asm_obs_dim(ctypes.byref(p)) == 188
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from marl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libAssemblyEnv.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_batched_env_refuses_cpu_device():
+    from marl_amd.batched import BatchedAssemblyEnv
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        BatchedAssemblyEnv(2, 30, device="cpu")
+
+
+def test_shapes_match_reference_table():
+    """n_g and l_cell of the seven shapes (survey of the reference's fig/*.png)."""
+    from marl_amd.shapes import load_shapes, otsu_threshold, grid_from_gray
+    l_cells, grids = load_shapes()
+    assert [g.shape[0] for g in grids] == [497, 487, 534, 516, 510, 502, 536]
+    np.testing.assert_allclose(l_cells, [0.061111, 0.057895, 0.066667, 0.064706, 0.062857, 0.070968, 0.062857], atol=5e-7)
+    for g in grids:
+        assert abs(g[:, 0].mean()) < 1e-12 and abs(g[:, 1].mean()) < 1e-12
+        assert g[:, 1].max() - g[:, 1].min() == pytest.approx(2.2)
+    # the pipeline itself on a synthetic image: a black 10 x 6 cell rectangle on white
+    img = np.full((36 * 10, 36 * 14), 255, np.uint8)
+    img[36:36 * 9, 36 * 2:36 * 12] = 0
+    assert otsu_threshold(img) < 255
+    l_cell, grid = grid_from_gray(img)
+    assert grid.shape == (6 * 8, 2)                      # the outermost ring of cells is skipped (cfg:64-65)
+    assert l_cell == pytest.approx(2.2 / 5)
+
+
+def test_gym_shim_semantics():
+    import marl_amd.gym as gym
+    from marl_amd.gym.core import TimeLimit
+    env = gym.make("AssemblySwarm-v0")
+    assert isinstance(env, TimeLimit) and env.spec.max_episode_steps == 100   # registration.py:105-110
+    base = env.unwrapped
+    assert type(base).__name__ == "AssemblySwarmEnv" and base.unwrapped is base
+    assert (base.n_a, base.topo_nei_max, base.dt, base.k_ball, base.k_wall, base.c_wall) == (10, 6, 0.1, 30, 100, 5)
+    w = gym.Wrapper(base)
+    assert w.n_a == 10                                   # core.py:232-237 attribute forwarding
+    with pytest.raises(AttributeError):
+        w._private
+    w.env.alpha = 0.1
+    assert base.alpha == 0.1
+    box = gym.spaces.Box(-np.inf, np.inf, shape=(192, 30), dtype=np.float32)
+    assert box.shape == (192, 30) and box.dtype == np.float32
+
+
+def test_compat_import_gym_alias():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import gym; "
+            "from gym.wrappers import AssemblySwarmWrapper; from gym import spaces; "
+            "e = gym.make('AssemblySwarm-v0').unwrapped; print(type(e).__name__, AssemblySwarmWrapper.__name__)"
+            % (os.path.join(REPO, "marl_amd", "compat"), REPO))
+    out = subprocess.check_output([sys.executable, "-c", code], text=True)
+    assert out.split() == ["AssemblySwarmEnv", "AssemblySwarmWrapper"]
+
+
+def test_wrapper_metrics_match_reference_values():
+    """Vectorised metrics against values recorded from the reference wrapper."""
+    from marl_amd.gym.wrappers import AssemblySwarmWrapper
+    z = np.load(os.path.join(REPO, "tests", "golden", "metrics.npz"))
+    for k in range(int(z["count"])):
+        w = AssemblySwarmWrapper.__new__(AssemblySwarmWrapper)
+        class E:  # the attributes the metrics read
+            pass
+        e = E(); e.p = z[f"p_{k}"]; e.grid_center = z[f"grid_{k}"]; e.n_g = e.grid_center.shape[1]; e.n_a = e.p.shape[1]
+        e.r_avoid = float(z[f"r_avoid_{k}"]); e.is_collide_b2b = z[f"collide_{k}"]
+        w.env = e
+        m = w.get_formation_metrics()
+        assert m["coverage_rate"] == float(z[f"coverage_rate_{k}"])
+        assert m["num_collisions"] == int(z[f"num_collisions_{k}"])
+        for key, zk in (("distribution_uniformity",) * 2, ("voronoi_uniformity",) * 2, ("avg_distance_to_target",) * 2):
+            assert m[key] == pytest.approx(float(z[f"{zk}_{k}"]), rel=1e-12, abs=1e-14)
