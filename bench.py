@@ -92,6 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
     from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.sharding import shard_range, reduce_episode_stats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +108,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     E, n_a, K, W = args.envs_per_gpu, args.agents, args.steps, args.warmup
-    env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=rank * E, keep_indices=args.keep_indices)
+    env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0], keep_indices=args.keep_indices)
     env.reset(episode=0)
     ring = min(max(K, 1), 64)
     actions = torch.empty(ring, E, 2, n_a, dtype=torch.float32, device=device)
@@ -125,19 +126,13 @@ def main():
         for t in range(t0, t0 + n):
             env.step(actions[t % ring])
             if (t + 1) % EPISODE_LENGTH == 0:               # end of episode (TRAIN:99,107,177-197)
-                s = env.episode_stats()
-                if world > 1:
-                    dist.all_reduce(s)                       # RCCL SUM of 8 doubles over xGMI
-                totals.add_(s)
+                totals.add_(reduce_episode_stats(env.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
                 env.reset()
 
     # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
     run_steps(W)
-    s0 = env.episode_stats()
-    if world > 1:
-        dist.all_reduce(s0)
-    totals.add_(s0).zero_()
+    totals.add_(reduce_episode_stats(env.episode_stats())).zero_()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

@@ -98,6 +98,15 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.T_ravoid = thr_lt(P.r_avoid);
     P.T_contact = thr_lt(P.sizes2);
     P.T_v005 = thr_lt(0.05);
+    // fp32 screens: EPS bounds the relative difference between the fp32 and the double
+    // evaluation of a squared distance (< 4e-7) plus the rounding of the threshold itself
+    const double EPS = 2e-6;
+    P.Tsen_f = (float)P.T_sen;
+    P.Tsen_amb_f = (float)(EPS * P.T_sen);
+    P.Tsen_hi_f = (float)(P.T_sen * (1.0 + EPS));
+    P.Thalf_hi_f = (float)(P.T_half_le * (1.0 + EPS));
+    P.Tcontact_hi_f = (float)(P.T_contact * (1.0 + EPS));
+    P.inv2dsen_f = (float)(0.5 / P.d_sen);
     *out = P;
     return 0;
 }

@@ -159,6 +159,76 @@ __device__ __forceinline__ void cell_pass(const DevParams &P, bool active, doubl
     }
 }
 
+
+// v_med3_u32: the median of three unsigned values
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Single-precision screening pass over the cells for one agent (fp32 state only).
+//
+// s32 = fl32 evaluation of |cell - p|^2 differs from the double-precision value s the
+// reference decides on by at most a few 2^-24 relative (one rounding in each difference,
+// squared, plus product/fma roundings: < 4e-7).  With the margin EPS = 2e-6 every
+// decision below is either certain in fp32 or handed to the exact double evaluation:
+//   * sensed bit  s < T_sen      : sign of (s32 - T_sen); the smallest |s32 - T_sen| is
+//                                  tracked and, if within EPS*T_sen, the whole pass is redone exactly;
+//   * occupancy   s < T_half     : rare; candidates s32 < T_half*(1+EPS) are evaluated exactly in place;
+//   * nearest cell (first minimum): the two smallest keys (s32 bits with the low 5 bits replaced
+//                                  by the cell's position in its 32-cell word) are tracked; if the
+//                                  runner-up is within 2 truncated units (2^-17 relative) the pass is
+//                                  redone exactly, otherwise the minimum is certain and unique.
+// Returns false when the exact pass is required.
+__device__ __forceinline__ bool cell_pass_fast(const DevParams &P, float px, float py, const float *gx,
+                                               const float *gy, int i, unsigned *mask, unsigned *occ,
+                                               unsigned *cov, int &imin)
+{
+    unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu;
+    int G1w = 0;
+    float amb = __builtin_inff();
+    for (int w = 0; w < P.W; ++w) {
+        unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0;
+        const float4 *X = reinterpret_cast<const float4 *>(gx + w * 32);
+        const float4 *Y = reinterpret_cast<const float4 *>(gy + w * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 x4 = X[q], y4 = Y[q];
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = q * 4 + r;
+                const float rx = xs[r] - px, ry = ys[r] - py;
+                const float s = __builtin_fmaf(ry, ry, rx * rx);
+                const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)b;
+                k2 = umed3(k1, k2, key);
+                k1 = k1 < key ? k1 : key;
+                const float d = s - P.Tsen_f;
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(d), 31);   // (word << 1) | (s < T_sen)
+                amb = __builtin_fminf(amb, __builtin_fabsf(d));
+                if (s < P.Thalf_hi_f) {                                            // rare: exact evaluation
+                    const double rxd = (double)xs[r] - (double)px, ryd = (double)ys[r] - (double)py;
+                    const double sd = rxd * rxd + ryd * ryd;
+                    if (sd < P.T_half_le) {
+                        atomicOr(&occ[w], 1u << b);
+                        if (sd < P.T_half_lt) atomicOr(&cov[w], 1u << b);
+                    }
+                }
+            }
+        }
+        mask[(size_t)i * P.MW + w] = __brev(word);                                 // first cell ended up in bit 31
+        if (k1 < G1) G1w = w;
+        const unsigned t = G1 > k1 ? G1 : k1;
+        const unsigned m = G2 < k2 ? G2 : k2;
+        G2 = m < t ? m : t;
+        G1 = G1 < k1 ? G1 : k1;
+    }
+    imin = G1w * 32 + (int)(G1 & 31u);
+    return ((G2 >> 5) - (G1 >> 5) >= 2u) && (amb > P.Tsen_amb_f);
+}
+
 // Uniform-subsampled emission of a bit list: for k in [0, cap): f(k, cell or -1).
 // count <= cap: the k-th set bit; count > cap: bit number round(k*(count-1)/(cap-1))
 // (CPP:224-229, 246-251; std::round, half away from zero).
@@ -182,11 +252,17 @@ __device__ __forceinline__ void emit_list(BitIter &it, int count, int cap, F f)
 // ---------------------------------------------------------------------------------
 // Observation + reward of environment e for agent i on the state held in LDS.
 // CPP:23-356 (observation), CPP:359-631 (reward).  Must be reached by every thread.
+//
+// S = float takes single-precision screening paths wherever a decision is certain in
+// fp32 and falls back to the exact double evaluation otherwise (cell_pass_fast above;
+// the neighbour and reward screens below follow the same rule), so its decisions are
+// those of the all-double code; S = double is the all-double code.
 template <typename S>
 __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, double l_cell,
                         const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
                         int *sensed_g, int *occup_g, double *stats_g, int contact_pairs)
 {
+    constexpr bool F32 = sizeof(S) == 4;
     const int n_a = P.n_a;
     const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
     const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
@@ -198,16 +274,33 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
     double nn_min = __builtin_inf();
     if (active) {
-        for (int j = 0; j < n_a; ++j) {
-            double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py; // CPP:84
-            if (P.want_stats) { double su = rx * rx + ry * ry; if (su != 0 && su < nn_min) nn_min = su; }
-            if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
-            double s = rx * rx + ry * ry;                                // CPP:641
-            if (j != i && s < P.T_sen) {                                 // CPP:663, self removed CPP:677-681
-                double ks = s; int kj = j;
+        auto consider = [&](int j, double s) {                           // sorted insert, ties keep the lower index
+            double ks = s; int kj = j;
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    if (ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+            for (int q = 0; q < 6; ++q)
+                if (ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+        };
+        if (F32 && !P.periodic) {
+            const float pxf = (float)L.px[i], pyf = (float)L.py[i];
+            float nn32 = __builtin_inff(); int nnj = -1;
+            for (int j = 0; j < n_a; ++j) {
+                const float rx = (float)L.px[j] - pxf, ry = (float)L.py[j] - pyf;
+                const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+                if (P.want_stats && s32 < nn32 && s32 > 0.0f) { nn32 = s32; nnj = j; }
+                if (j != i && s32 < P.Tsen_hi_f) {                       // candidates only: exact evaluation
+                    const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                    const double s = dx * dx + dy * dy;                  // CPP:641
+                    if (s < P.T_sen) consider(j, s);                     // CPP:663, self removed CPP:677-681
+                }
+            }
+            if (nnj >= 0) { const double dx = (double)L.px[nnj] - px, dy = (double)L.py[nnj] - py; nn_min = dx * dx + dy * dy; }
+        } else {
+            for (int j = 0; j < n_a; ++j) {
+                double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py; // CPP:84
+                if (P.want_stats) { double su = rx * rx + ry * ry; if (su != 0 && su < nn_min) nn_min = su; }
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
+                const double s = rx * rx + ry * ry;                          // CPP:641
+                if (j != i && s < P.T_sen) consider(j, s);
             }
         }
         // agent block, column-major flatten of rows [pos_x,pos_y,vel_x,vel_y] (CPP:108-131)
@@ -238,8 +331,16 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
     for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
     __syncthreads();
-    double smin; int imin;
-    cell_pass<S, true>(P, active, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
+    double smin = 0.0; int imin = 0;
+    if (active) {
+        bool done = false;
+        if constexpr (F32) {
+            done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
+                                  reinterpret_cast<const float *>(L.gy), i, L.mask, L.occ, L.cov, imin);
+            if (done) { const double rx = (double)L.gx[imin] - px, ry = (double)L.gy[imin] - py; smin = rx * rx + ry * ry; }
+        }
+        if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
+    }
     const double dmin = sqrt(smin);
     const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
     __syncthreads();
@@ -276,28 +377,65 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     // ---- sensed list (CPP:243-296) and exploration reward terms (CPP:499-557) ----
+    // psi = rho_cos_dec(z, 0, d_sen), CPP:1017-1025
+    auto psi_exact = [&](double gx, double gy) {
+        const double z = sqrt(gx * gx + gy * gy);                        // CPP:524
+        if (z < 0.0 * P.d_sen) return 1.0;
+        else if (z < P.d_sen) return (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+        return 0.0;
+    };
     double num0 = 0.0, num1 = 0.0, den = 0.0;
+    bool uniform = false, uniform_known = false;
     if (active) {
         BitIter it; it.init(mym, P.W, in_flag ? L.occ : nullptr, true);
         int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * P.n_obs : nullptr;
         const int gb = P.obs_dim - P.n_obs * 2;
         const bool cart = P.cartesian != 0;
-        emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
-            double gx = 0.0, gy = 0.0;
-            if (cell >= 0) {
-                gx = (double)L.gx[cell] - px; gy = (double)L.gy[cell] - py;      // CPP:285-286, 515-516
-                if (in_flag && P.want_reward) {
-                    double z = sqrt(gx * gx + gy * gy);                          // CPP:524
-                    double psi;                                                  // CPP:1017-1025, delta = 0
-                    if (z < 0.0 * P.d_sen) psi = 1.0;
-                    else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
-                    else psi = 0.0;
-                    num0 += psi * gx; num1 += psi * gy; den += psi;              // CPP:537-539
+        const bool rew_on = in_flag && P.want_reward;
+        if constexpr (F32) {
+            // values: fl32(cell - p) is the correctly rounded difference either way; reward
+            // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within 2e-4 of 0.05
+            const float pxf = (float)L.px[i], pyf = (float)L.py[i];
+            float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+            emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+                float gx = 0.f, gy = 0.f;
+                if (cell >= 0) {
+                    gx = (float)L.gx[cell] - pxf; gy = (float)L.gy[cell] - pyf;          // CPP:285-286
+                    if (rew_on) {
+                        const float z = __builtin_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float psi = 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f);   // cos(pi z / d_sen)
+                        fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
+                    }
                 }
+                ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy;
+                if (sdst) sdst[k] = cell;
+            });
+            if (rew_on && n_after > 0 && fden > 0.f) {
+                const float v0 = fn0 / fden, v1 = fn1 / fden;
+                const float vn = __builtin_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                if (__builtin_fabsf(vn - 0.05f) > 2e-4f) { uniform = vn < 0.05f; uniform_known = true; }
             }
-            if (cart) { ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy; }
-            if (sdst) sdst[k] = cell;
-        });
+            if (rew_on && n_after > 0 && !uniform_known) {               // borderline: the exact sums
+                BitIter it2; it2.init(mym, P.W, L.occ, true);
+                emit_list(it2, n_after, P.n_obs, [&](int, int cell) {
+                    if (cell >= 0) {
+                        const double gx = (double)L.gx[cell] - px, gy = (double)L.gy[cell] - py;
+                        const double psi = psi_exact(gx, gy);
+                        num0 += psi * gx; num1 += psi * gy; den += psi;
+                    }
+                });
+            }
+        } else {
+            emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+                double gx = 0.0, gy = 0.0;
+                if (cell >= 0) {
+                    gx = (double)L.gx[cell] - px; gy = (double)L.gy[cell] - py;          // CPP:285-286, 515-516
+                    if (rew_on) { const double psi = psi_exact(gx, gy); num0 += psi * gx; num1 += psi * gy; den += psi; }  // CPP:537-539
+                }
+                if (cart) { ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy; }
+                if (sdst) sdst[k] = cell;
+            });
+        }
     }
 
     // ---- reward: CPP:457-564 ----
@@ -313,8 +451,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 if (rx * rx + ry * ry < P.T_ravoid) collision = true;    // CPP:487 r_avoid > norm
             }
         }
-        bool uniform = false;
-        if (in_flag && n_after > 0) {
+        if (in_flag && n_after > 0 && !uniform_known) {
             if (den == 0) den = 1E-8;                                    // CPP:542-544
             double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;         // CPP:547-548
             uniform = v0 * v0 + v1 * v1 < P.T_v005;                      // CPP:550-552
@@ -415,6 +552,10 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
         double fx = 0.0, fy = 0.0;
         for (int k = 0; k < n_a; ++k) {
             if (k == i) continue;
+            if (sizeof(S) == 4) {                                                // fp32 screen: certain misses
+                const float fx32 = (float)L.px[k] - (float)L.px[i], fy32 = (float)L.py[k] - (float)L.py[i];
+                if (!(__builtin_fmaf(fy32, fy32, fx32 * fx32) < P.Tcontact_hi_f) && !(P.want_stats && P.periodic && i == 0)) continue;
+            }
             double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;         // CPP:782-785 (delta = p_k - p_i)
             double s = dx * dx + dy * dy;                                        // ENV:444 (no wrap for rows >= 1)
             if (s < P.T_contact) {                                               // ENV:445-446 d - sizes < 0

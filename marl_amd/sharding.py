@@ -1,0 +1,47 @@
+"""Multi-GPU glue of the batched environment: environments are independent, so ranks
+own contiguous ranges of GLOBAL environment ids (the reset generator is keyed by that
+id, so any split yields the same environments) and the only collective is one SUM
+all-reduce of the 8-value episode-statistics vector per episode (RCCL over xGMI on
+GPUs; the same code runs on gloo for CPU tests)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+STATS_FIELDS = ("reward_sum", "reward_sq_sum", "coverage_sum", "uniformity_sum", "contact_pairs_sum",
+                "avg_distance_sum", "env_steps", "agents_inside_sum")
+
+
+def shard_range(rank: int, world: int, envs_per_rank: int) -> Tuple[int, int]:
+    """(first global env id, count) of `rank` for weak scaling: every rank owns envs_per_rank ids."""
+    if not (0 <= rank < world) or envs_per_rank < 1:
+        raise ValueError("bad shard request")
+    return rank * envs_per_rank, envs_per_rank
+
+
+def split_range(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first id, count) for strong scaling: `total_envs` ids split as evenly as possible."""
+    base, rem = divmod(total_envs, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def reduce_episode_stats(local_stats: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Sum the per-rank [8] float64 vector over all ranks (in place) and return it."""
+    if local_stats.shape != (8,) or local_stats.dtype != torch.float64:
+        raise ValueError("episode statistics are 8 float64 values")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_stats, op=dist.ReduceOp.SUM, group=group)
+    return local_stats
+
+
+def summarize(stats: torch.Tensor, n_a: int) -> dict:
+    """Episode means as TRAIN:164-197 logs them, from the reduced vector."""
+    s = stats.tolist()
+    steps = max(s[6], 1.0)
+    mean_r = s[0] / (steps * n_a)
+    return {"reward_mean": mean_r, "reward_std": max(s[1] / (steps * n_a) - mean_r ** 2, 0.0) ** 0.5,
+            "coverage": s[2] / steps, "uniformity": s[3] / steps, "collisions_per_step": s[4] / steps,
+            "avg_distance_to_target": s[5] / steps, "inside_fraction": s[7] / (steps * n_a)}
