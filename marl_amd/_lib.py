@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "build", "libAssemblyEnv.so")
+# MARL_AMD_LIB: load another build of the same library (e.g. the diagnostic build of `make diag`)
+SO_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "csrc", "build", "libAssemblyEnv.so")
 
 ABI_VERSION = 1
 

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -98,15 +99,29 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.T_ravoid = thr_lt(P.r_avoid);
     P.T_contact = thr_lt(P.sizes2);
     P.T_v005 = thr_lt(0.05);
-    // fp32 screens: EPS bounds the relative difference between the fp32 and the double
-    // evaluation of a squared distance (< 4e-7) plus the rounding of the threshold itself
-    const double EPS = 2e-6;
+    // fp32 screens: the fp32 evaluation of a squared distance (two rounded differences, a product, an fma)
+    // is within 4 * 2^-24 = 2.4e-7 relative of the double one, the fp32 threshold within 2^-24 = 6e-8 of
+    // the double threshold; EPS = 5e-7 covers both with margin
+    const double EPS = 5e-7;
     P.Tsen_f = (float)P.T_sen;
     P.Tsen_amb_f = (float)(EPS * P.T_sen);
     P.Tsen_hi_f = (float)(P.T_sen * (1.0 + EPS));
     P.Thalf_hi_f = (float)(P.T_half_le * (1.0 + EPS));
     P.Tcontact_hi_f = (float)(P.T_contact * (1.0 + EPS));
     P.inv2dsen_f = (float)(0.5 / P.d_sen);
+    // k_step_fast eligibility and geometry (fp32 state only; see asm_kernels.hip)
+    P.capp = (P.n_obs + 7) / 8 * 8;
+    P.fast_T = 0;
+    if (state_bytes == 4 && prm->n_a <= 32 && !P.periodic && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
+        const int blocks = (E + 1) / 2;
+        int T = blocks <= 2048 ? 4 : (blocks <= 4096 ? 2 : 1);       // enough waves to fill 256 CUs
+        if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
+        if (T == 1 || T == 2 || T == 4) {
+            const size_t bytes = 4 * (256 + 4 * (size_t)P.NGP + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
+                                 4 * 64 + 4 * 3 * 64 * (size_t)T + std::max(2 * 64 * (size_t)P.capp, 4 * 64 * (size_t)P.MW);
+            if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
+        }
+    }
     *out = P;
     return 0;
 }
@@ -215,8 +230,11 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
         return fail(1, "asm_batch_step_f32: NULL required pointer");
     P.want_reward = 1; P.want_stats = stats != nullptr; P.recompute = recompute_target != 0;
     if (!a_prior) P.prior = 0;
-    int rc = asmenv::launch_step<float>(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
-                                        reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
+    int rc = P.fast_T
+        ? asmenv::launch_step_fast(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
+                                   a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream)
+        : asmenv::launch_step<float>(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+                                     reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_batch_step_f32") : 0;
 }
 
@@ -244,6 +262,11 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
     int rc = asmenv::launch_random_actions(seed, step, env0, E, n_a, act, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_batch_random_actions_f32") : 0;
 }
+
+#ifdef ASM_DIAG
+// diagnostic build only: device buffer [grid][16] of cycle stamps, or NULL to stop stamping
+int asm_diag_set_buffer(void *dev) { return asmenv::diag_set_buffer((unsigned long long *)dev); }
+#endif
 
 int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream)
 {

@@ -17,6 +17,8 @@ struct DevParams {
     int n_g_e;                      // set per environment inside the kernels
     int block, grid;
     unsigned lds_env_bytes, lds_block_bytes;
+    int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
+    unsigned fast_lds_bytes;
     double T_sen;                   // norm < d_sen            CPP:663, 907
     double T_half_le;               // !(norm > r_avoid/2)     CPP:190
     double T_half_lt;               // norm < r_avoid/2        WRAP:67
@@ -41,6 +43,9 @@ int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t en
                  const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,
                  int *shape_id, S *p, S *dp, S *grid, int *n_g, double *l_cell, int *nbr, int *inflags, int *nearest,
                  S *obs, int *sensed, int *occupied, hipStream_t st);
+int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, const float *grid, const int *n_g,
+                     const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
+                     int *sensed, int *occupied, double *stats, hipStream_t st);
 int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st);
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st);
 int launch_reward_compat(const DevParams &P, const double *p, const double *grid, int n_g, const int *nbr,
@@ -52,5 +57,9 @@ int launch_dist_b2w_compat(const double *p, const double *r, int n_a, const doub
                            bool *coll, hipStream_t st);
 int launch_prior_compat(const DevParams &P, const double *p, const double *dp, const double *grid, int n_g,
                         const int *nbr, double l_cell, double *a_prior, hipStream_t st);
+
+#ifdef ASM_DIAG
+int diag_set_buffer(unsigned long long *dev);
+#endif
 
 }  // namespace asmenv

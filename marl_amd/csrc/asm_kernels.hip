@@ -29,6 +29,16 @@ namespace asmenv {
 
 #define ASM_PI 3.14159265358979323846
 
+// Diagnostic build only (make diag): cycle stamps at phase boundaries, written by lane 0
+// of each workgroup's first wave to a buffer of its own.  The product build has no stamps.
+#ifdef ASM_DIAG
+__device__ unsigned long long *g_diag = nullptr;          // [grid][16]
+#define STAMP(k) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+    if ((k) == 0) g_diag[(size_t)blockIdx.x * 16 + 10] = wall_clock64(); if ((k) == 9) g_diag[(size_t)blockIdx.x * 16 + 11] = wall_clock64(); } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double hh)
 {   // CPP:705-720
     if (x < -hw) x += 2 * hw; else if (x > hw) x -= 2 * hw;
@@ -328,6 +338,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         }
     }
 
+    STAMP(4);
     // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
     for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
     __syncthreads();
@@ -341,6 +352,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         }
         if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
     }
+    STAMP(5);
     const double dmin = sqrt(smin);
     const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
     __syncthreads();
@@ -376,6 +388,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         }
     }
 
+    STAMP(6);
     // ---- sensed list (CPP:243-296) and exploration reward terms (CPP:499-557) ----
     // psi = rho_cos_dec(z, 0, d_sen), CPP:1017-1025
     auto psi_exact = [&](double gx, double gy) {
@@ -438,6 +451,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         }
     }
 
+    STAMP(7);
     // ---- reward: CPP:457-564 ----
     double reward = 0.0;
     if (active && P.want_reward) {
@@ -460,6 +474,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if (rew_g) rew_g[(size_t)e * n_a + i] = (S)reward;
     }
 
+    STAMP(8);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
     if (P.want_stats) {
         __syncthreads();                                                 // masks no longer needed
@@ -487,6 +502,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
         }
     }
+    STAMP(9);
 }
 
 // Loads the environment's grid (padded with far-away cells) and state into LDS.
@@ -539,10 +555,12 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a;
     EnvLds<S> L = carve<S>(smem, P, es);
+    STAMP(0);
     const int n_g = env_ok ? ng_g[e] : 0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     __syncthreads();
+    STAMP(1);
 
     double npx = 0, npy = 0, nvx = 0, nvy = 0;
     int contacts = 0;
@@ -622,6 +640,7 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
             if (npy > P.half_h) npy -= 2 * P.half_h;
         }
     }
+    STAMP(2);
     // contact pairs of the environment (upper triangle, WRAP:141-145)
     int contact_pairs = 0;
     if (P.want_stats) {
@@ -641,9 +660,566 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
         p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = d;
     }
     __syncthreads();
+    STAMP(3);
     DevParams Q = P; Q.n_g_e = n_g;
     observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
                stats_g, contact_pairs);
+}
+
+// =====================================================================================
+// k_step_fast<T>: the step kernel for the common shape of the problem — fp32 state, at most 32
+// agents per environment, walls on (no periodic wrap), at most 1024 grid cells, n_g_max a
+// multiple of 32.  Same results as k_step<float> (the tests compare them bit for bit); the
+// difference is the schedule:
+//   * a workgroup = T wavefronts (T = 1, 2, 4) working on TWO environments; lane l of every
+//     wavefront is agent (l & 31) of environment (l >> 5), so all T waves see the same agents
+//     and every "which wave does what" branch is wave-uniform;
+//   * the agent x cell pass is split over the T waves by 32-cell words; the sensed-cell lists
+//     are compacted into LDS by words (ranks from per-word popcounts) and the 80 observation
+//     slots are then written slot-range by slot-range, every store a full row segment;
+//   * pair loops (contacts, k-NN) screen all 32 candidates in fp32 into a bit mask and run the
+//     exact double evaluation only on the set bits.
+// T is chosen by the host so that a launch has enough waves to fill the chip.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct FastLds {
+    float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
+    float *g;                      // [2][2][NGP]  per env: x row, y row; cells >= n_g hold 1e30
+    unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
+    unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
+    uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
+    unsigned *fin;                 // [64]         nearest cell | in_flag << 31
+    float *rpart;                  // [T][3][64]   per-wave partial reward sums
+    unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
+};
+
+__device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T)
+{
+    FastLds L;
+    float *f = reinterpret_cast<float *>(smem);
+    L.px = f; L.py = f + 64; L.vx = f + 128; L.vy = f + 192;
+    L.g = f + 256;
+    L.mask = reinterpret_cast<unsigned *>(L.g + 4 * P.NGP);
+    L.occ = L.mask + 64 * P.MW;
+    L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
+    L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
+    L.rpart = reinterpret_cast<float *>(L.fin + 64);
+    L.sel = reinterpret_cast<unsigned short *>(L.rpart + 3 * 64 * T);
+    return L;
+}
+
+// sum / min / max over the 32 lanes of an environment half
+__device__ __forceinline__ double half_sum(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+    return v;
+}
+__device__ __forceinline__ double half_min(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 32));
+    return v;
+}
+__device__ __forceinline__ double half_max(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 32));
+    return v;
+}
+
+#ifndef ASM_FAST_MINW
+#define ASM_FAST_MINW 1
+#endif
+template <int T>
+__global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
+                                                      const float *grid_g, const int *ng_g, const double *lcell_g,
+                                                      int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
+                                                      float *rew_g, float *prior_g, int *sensed_g, int *occup_g,
+                                                      double *stats_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, sub = tid >> 6, l = tid & 63, es = l >> 5, i = l & 31;
+    const int e = blockIdx.x * 2 + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
+    const FastLds L = carve_fast(smem, P, T);
+    float *gxe = L.g + (size_t)es * 2 * NGP, *gye = gxe + NGP;
+    unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
+    constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
+    STAMP(0);
+
+    // ---- P0: grid and state into LDS --------------------------------------------------
+    {
+        const int per_env4 = NGP / 2;                               // float4 per environment (2 rows)
+        for (int base = 0; base < NGP; base += 64 * T * 4) {
+            float4 v[4]; int idx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                idx[q] = base + q * 64 * T + tid;
+                v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                if (idx[q] < NGP) {
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4, eh = blockIdx.x * 2 + h;
+                    if (eh < P.E) v[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)eh * 2 * NGP + (size_t)r * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (idx[q] < NGP) {
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4, eh = blockIdx.x * 2 + h;
+                    const int ngh = eh < P.E ? ng_g[eh] : 0;
+                    const int c = r * 4 - (r * 4 >= NGP ? NGP : 0);
+                    float4 u = v[q];
+                    if (c + 0 >= ngh) u.x = 1e30f;
+                    if (c + 1 >= ngh) u.y = 1e30f;
+                    if (c + 2 >= ngh) u.z = 1e30f;
+                    if (c + 3 >= ngh) u.w = 1e30f;
+                    *reinterpret_cast<float4 *>(L.g + (size_t)idx[q] * 4) = u;
+                }
+            }
+        }
+        for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
+        if (sub == 0) {
+            float a = 1e30f, b = 1e30f, c = 0.f, d = 0.f;
+            if (active) {
+                const size_t o = (size_t)e * 2 * n_a;
+                a = p_g[o + i]; b = p_g[o + n_a + i]; c = dp_g[o + i]; d = dp_g[o + n_a + i];
+            }
+            L.px[l] = a; L.py[l] = b; L.vx[l] = c; L.vy[l] = d;
+        }
+    }
+    const int n_g = env_ok ? ng_g[e] : 1;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    __syncthreads();
+    STAMP(1);
+
+    // ---- P1: forces, prior and integration on the OLD state (ENV:486-647) -------------
+    float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
+    int contacts = 0;
+    if (sub == 0 && active) {
+        const float pxf = L.px[l], pyf = L.py[l];
+        const double px = pxf, py = pyf, vx = L.vx[l], vy = L.vy[l];
+        unsigned cc = 0;                                            // fp32 screen of the 32 slots
+#pragma unroll
+        for (int j4 = 0; j4 < 32; j4 += 4) {
+            const float4 X = *reinterpret_cast<const float4 *>(L.px + es * 32 + j4);
+            const float4 Y = *reinterpret_cast<const float4 *>(L.py + es * 32 + j4);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rx = xs[r] - pxf, ry = ys[r] - pyf;
+                const float s = __builtin_fmaf(ry, ry, rx * rx);
+                cc = __builtin_amdgcn_alignbit(cc, __float_as_uint(s - P.Tcontact_hi_f), 31);
+            }
+        }
+        cc = __brev(cc) & ~(1u << i);
+        double fx = 0.0, fy = 0.0;                                  // ENV:437-452 + CPP:740-820, ascending k
+        while (cc) {
+            const int k = __ffs(cc) - 1; cc &= cc - 1;
+            const double dx = (double)L.px[es * 32 + k] - px, dy = (double)L.py[es * 32 + k] - py;   // CPP:782-785
+            const double s = dx * dx + dy * dy;                     // ENV:444
+            if (s < P.T_contact) {                                  // ENV:445-446
+                const double d = sqrt(s);
+                const double gap = fabs(d - P.sizes2);              // ENV:447
+                fx += 1.0 * gap * P.k_ball * (-(dx / d));           // CPP:790-793
+                fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                if (k > i) ++contacts;
+            }
+        }
+        // walls: CPP:822-860, ENV:510-513
+        const double r = P.size_a;
+        const double d0 = px - r - (-P.half_w), d1 = P.half_h - (py + r);       // CPP:841-842
+        const double d2 = P.half_w - (px + r), d3 = py - r - (-P.half_h);       // CPP:843-844
+        const bool c0 = d0 < 0, c1 = d1 < 0, c2 = d2 < 0, c3 = d3 < 0;          // CPP:849
+        const double a0 = c0 ? fabs(d0) : 0.0, a1 = c1 ? fabs(d1) : 0.0, a2 = c2 ? fabs(d2) : 0.0, a3 = c3 ? fabs(d3) : 0.0;
+        const double wfx = (a0 - a2) * P.k_wall, wfy = (-a1 + a3) * P.k_wall;   // ENV:512
+        const double dfx = (-(c0 ? vx : 0.0) + -(c2 ? vx : 0.0)) * P.c_wall;    // ENV:513
+        const double dfy = (-(c1 ? vy : 0.0) + -(c3 ? vy : 0.0)) * P.c_wall;
+        // integration: ENV:626-647
+        const float sens = (float)P.sens;
+        const double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);       // ENV:627,633
+        const double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        const double Fx = ux + fx + wfx + dfx, Fy = uy + fy + wfy + dfy;         // ENV:633
+        double ax = Fx, ay = Fy;
+        if (P.mass != 1.0) { ax = Fx / P.mass; ay = Fy / P.mass; }               // ENV:638 (x / 1 == x)
+        double v0 = vx + ax * P.dt, v1 = vy + ay * P.dt;                         // ENV:641
+        v0 = fmin(fmax(v0, -P.vel_max), P.vel_max); v1 = fmin(fmax(v1, -P.vel_max), P.vel_max);   // ENV:642
+        npx = (float)(px + v0 * P.dt); npy = (float)(py + v1 * P.dt);            // ENV:645
+        nvx = (float)v0; nvy = (float)v1;
+    }
+    if (sub == SUB_PRIOR && active && P.prior && prior_g) {         // ENV:600-619: old state, previous neighbour list
+        const double px = L.px[l], py = L.py[l], vx = L.vx[l], vy = L.vy[l];
+        int nb[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+        bool inf; int near;
+        if (P.recompute) {
+            double smin; cell_pass<float, false>(P, true, px, py, gxe, gye, l, nullptr, nullptr, nullptr, smin, near);
+            inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
+        } else {
+            inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
+        }
+        const double tx = inf ? px : (double)gxe[near], ty = inf ? py : (double)gye[near];      // CPP:896-901
+        double f0, f1;
+        prior_policy<float>(P, px, py, vx, vy, tx, ty, nb, L.px + es * 32, L.py + es * 32, L.vx + es * 32,
+                            L.vy + es * 32, f0, f1);
+        prior_g[(size_t)e * 2 * n_a + i] = (float)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (float)f1;
+    }
+    STAMP(2);
+    __syncthreads();                                                // all reads of the old state done
+    if (sub == 0 && active) {
+        L.px[l] = npx; L.py[l] = npy; L.vx[l] = nvx; L.vy[l] = nvy;
+        const size_t o = (size_t)e * 2 * n_a;
+        p_g[o + i] = npx; p_g[o + n_a + i] = npy; dp_g[o + i] = nvx; dp_g[o + n_a + i] = nvy;
+    }
+    __syncthreads();
+    STAMP(3);
+
+    // ---- P3: agent x cell pass on the NEW state, words split over the waves ------------
+    const float pxf = L.px[l], pyf = L.py[l];
+    const double px = pxf, py = pyf;
+    float *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;          // obs[row * n_a + agent]
+    double s6[6]; int j6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
+    double nn_min = __builtin_inf();
+    if (sub == 0 && active) {
+        // k nearest neighbours inside d_sen (_get_focused, CPP:633-703): fp32 screen, exact on candidates
+        unsigned cand = 0, n1 = 0xFFFFFFFFu, n2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j4 = 0; j4 < 32; j4 += 4) {
+            const float4 X = *reinterpret_cast<const float4 *>(L.px + es * 32 + j4);
+            const float4 Y = *reinterpret_cast<const float4 *>(L.py + es * 32 + j4);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rx = xs[r] - pxf, ry = ys[r] - pyf;
+                const float s = __builtin_fmaf(ry, ry, rx * rx);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(s - P.Tsen_hi_f), 31);
+                const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)(j4 + r);   // two smallest: self (0)
+                n2 = umed3(n1, n2, key); n1 = n1 < key ? n1 : key;                        // and the nearest neighbour
+            }
+        }
+        cand = __brev(cand) & ~(1u << i);
+        while (cand) {                                              // ascending j: ties keep the lower index
+            const int j = __ffs(cand) - 1; cand &= cand - 1;
+            const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+            const double s = dx * dx + dy * dy;                     // CPP:641
+            if (s < P.T_sen) {                                      // CPP:663; self removed CPP:677-681
+                double ks = s; int kj = j;
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    if (ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+            }
+        }
+        if (P.want_stats && n_a > 1) {
+            const int nj = (int)((n1 & 31u) == (unsigned)i ? (n2 & 31u) : (n1 & 31u));
+            const double dx = (double)L.px[es * 32 + nj] - px, dy = (double)L.py[es * 32 + nj] - py;
+            nn_min = dx * dx + dy * dy;
+        }
+        // agent block, rows [pos_x,pos_y,vel_x,vel_y] per column (CPP:108-131); fl32(a - b) is the
+        // correctly rounded difference, identical to rounding the double difference
+        const float vxf = L.vx[l], vyf = L.vy[l];
+        int r0 = 0;
+        if (P.con_self) { ocol[0] = pxf; ocol[(size_t)n_a] = pyf; ocol[(size_t)2 * n_a] = vxf; ocol[(size_t)3 * n_a] = vyf; r0 = 4; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int j = j6[q];
+            float rx = 0.f, ry = 0.f, wx = 0.f, wy = 0.f;
+            if (j >= 0) {
+                rx = L.px[es * 32 + j] - pxf; ry = L.py[es * 32 + j] - pyf;
+                wx = L.vx[es * 32 + j] - vxf; wy = L.vy[es * 32 + j] - vyf;      // CPP:86
+            }
+            nbr_g[((size_t)e * n_a + i) * 6 + q] = j;               // CPP:103-105
+            const size_t r = (size_t)(r0 + 4 * q) * n_a;
+            ocol[r] = rx; ocol[r + n_a] = ry; ocol[r + 2 * (size_t)n_a] = wx; ocol[r + 3 * (size_t)n_a] = wy;
+        }
+    }
+    STAMP(4);
+    {
+        // single-precision screening pass (see cell_pass_fast for the error argument)
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;   // ambw: words with an undecided sensed bit
+        unsigned *wkey = reinterpret_cast<unsigned *>(L.sel);       // [64][MW], aliases the slot lists (written later)
+        const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+        const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
+        for (int w = sub; w < W; w += T) {
+            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
+            float amb = __builtin_inff();
+            const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
+            const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x4 = X[q], y4 = Y[q];
+                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                const float ss[4] = {sa.x, sa.y, sb.x, sb.y};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = q * 4 + r;
+                    const float s = ss[r];
+                    const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)b;
+                    k2 = umed3(k1, k2, key);
+                    k1 = k1 < key ? k1 : key;
+                    const f32x2 s2 = {s, s};
+                    const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half_hi)
+                    word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
+                    ocand = __builtin_amdgcn_alignbit(ocand, __float_as_uint(d.y), 31);
+                    amb = __builtin_fminf(amb, __builtin_fabsf(d.x));
+                }
+            }
+            L.mask[(size_t)l * MW + w] = __brev(word);
+            wkey[(size_t)l * MW + w] = k1;                           // smallest key of the word, for the rare tie resolution
+            if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
+            ocand = __brev(ocand);
+            if (!active) ocand = 0;
+            while (ocand) {                                         // rare: exact occupancy / coverage test
+                const int b = __ffs(ocand) - 1; ocand &= ocand - 1;
+                const double rxd = (double)gxe[w * 32 + b] - px, ryd = (double)gye[w * 32 + b] - py;
+                const double sd = rxd * rxd + ryd * ryd;
+                if (sd < P.T_half_le) {                             // CPP:190  !(norm > r_avoid/2)
+                    atomicOr(&occ_e[w], 1u << b);
+                    if (sd < P.T_half_lt) atomicOr(&cov_e[w], 1u << b);   // WRAP:67
+                }
+            }
+            if (k1 < G1) G1w = (unsigned)w;
+            const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
+            G2 = m < t ? m : t;
+            G1 = G1 < k1 ? G1 : k1;
+        }
+        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, ambw);
+    }
+    STAMP(5);
+    __syncthreads();
+    STAMP(12);
+
+    // ---- P4 (wave 0): nearest cell, in-shape flag, target block -------------------------
+    double dmin = 0.0;
+    if (sub == 0) {
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const uint4 q = L.part[s * 64 + l];
+            if (q.x < G1) G1w = q.z;
+            const unsigned t = G1 > q.x ? G1 : q.x, m = G2 < q.y ? G2 : q.y;
+            G2 = m < t ? m : t;
+            G1 = G1 < q.x ? G1 : q.x;
+            ambw |= q.w;
+        }
+        int imin = (int)(G1w * 32 + (G1 & 31u));
+        double smin;
+        if (active) {
+            const bool amb_min = !((G2 >> 5) - (G1 >> 5) >= 2u);
+#ifdef ASM_DIAG
+            if (g_diag && (amb_min || ambw)) atomicAdd(&g_diag[(size_t)blockIdx.x * 16 + 15], amb_min ? 1000ull : 1ull);
+#endif
+            if (amb_min) {                                          // words holding a candidate for the minimum
+                const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
+                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - (G1 >> 5) < 2u) ambw |= 1u << w;
+            }
+            if (ambw) {
+                // Rare.  Re-run the fp32 screen on the flagged words (same arithmetic, so the same s32) and
+                // evaluate exactly only the cells the screen could not decide: those within the margin of
+                // T_sen, and the candidates for the minimum (truncated key within 2 units of the smallest;
+                // ascending index + strict '<' gives the reference's first minimum, CPP:889).
+                double best = __builtin_inf(); int besti = imin;
+                const unsigned lo = G1 >> 5;
+                unsigned *mw = L.mask + (size_t)l * MW;
+                while (ambw) {
+                    const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
+                    unsigned word = mw[w];
+#pragma unroll 4
+                    for (int b = 0; b < 32; ++b) {
+                        const int c = w * 32 + b;
+                        const float rx = gxe[c] - pxf, ry = gye[c] - pyf;
+                        const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+                        const bool a = __builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f;
+                        const bool m = amb_min && ((__float_as_uint(s32) >> 5) - lo < 2u);
+                        if (a || m) {
+                            const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
+                            const double sd = dx * dx + dy * dy;
+                            if (a) { if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b); }
+                            if (m && sd < best) { best = sd; besti = c; }
+                        }
+                    }
+                    mw[w] = word;
+                }
+                if (amb_min) imin = besti;
+            }
+            { const double rx = (double)gxe[imin] - px, ry = (double)gye[imin] - py; smin = rx * rx + ry * ry; }
+            dmin = sqrt(smin);
+            const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;     // CPP:894
+            L.fin[l] = (unsigned)imin | (in_flag ? 0x80000000u : 0u);
+            inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;        // CPP:139
+            nearest_g[(size_t)e * n_a + i] = imin;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
+            if (!in_flag) { t0 = gxe[imin] - pxf; t1 = gye[imin] - pyf; t2 = 0.f - L.vx[l]; t3 = 0.f - L.vy[l]; }
+            const int tb = P.obs_dim - (2 + cap) * 2;               // CPP:304
+            ocol[(size_t)(tb + 0) * n_a] = t0; ocol[(size_t)(tb + 1) * n_a] = t1;
+            ocol[(size_t)(tb + 2) * n_a] = t2; ocol[(size_t)(tb + 3) * n_a] = t3;
+        } else {
+            L.fin[l] = 0;
+        }
+    }
+    STAMP(13);
+    __syncthreads();
+    STAMP(14);
+
+    // ---- P5: compaction of the sensed lists into LDS, by words --------------------------
+    const unsigned fin = L.fin[l];
+    const bool in_flag = (fin >> 31) != 0;
+    const unsigned *mym = L.mask + (size_t)l * MW;
+    int n_before = 0, n_occ = 0;
+    unsigned nz = 0;                                                // words with a cell that stays in the list
+    for (int w = 0; w < W; ++w) {
+        const unsigned m = mym[w];
+        const unsigned o = in_flag ? m & occ_e[w] : 0u;             // CPP:155: only when inside the shape
+        n_before += __popc(m); n_occ += __popc(o);
+        if (m & ~o) nz |= 1u << w;
+    }
+    const int n_after = active ? n_before - n_occ : 0;
+    const int n_out = n_after < cap ? n_after : cap;
+    unsigned short *mysel = L.sel + (size_t)l * P.capp;
+    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots
+    {
+        // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
+        // rank k.  cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double
+        // evaluation rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced
+        // incrementally as quotient/remainder.  For n <= cap the increment is exactly 1.
+        // One loop per lane over its own set bits (non-empty words only): the wave iterates as often as
+        // its busiest lane needs, not once per word and busiest lane.
+        const unsigned two_c = 2u * (unsigned)(cap - 1);
+        const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
+        const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
+        const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
+        unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
+        int rank = 0, k = k0, w = 0;
+        bool busy = active && n_after > 0 && k0 < n_out;
+        while (busy) {
+            if (bits == 0) {
+                if (nz == 0) { busy = false; continue; }
+                w = __ffs(nz) - 1; nz &= nz - 1;
+                bits = mym[w];
+                if (in_flag) bits &= ~occ_e[w];
+                const int pc = __popc(bits);
+                if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+            }
+            const int b = __ffs(bits) - 1; bits &= bits - 1;
+            if ((unsigned)rank == tq) {
+                mysel[k] = (unsigned short)(w * 32 + b);
+                ++k; tq += inc_q; tr += inc_r;
+                if (tr >= two_c) { tr -= two_c; ++tq; }
+                if (k >= k1 || k >= n_out) busy = false;
+            }
+            ++rank;
+        }
+    }
+    if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
+        int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
+        BitIter it; it.init(mym, W, occ_e, false);
+        emit_list(it, in_flag ? n_occ : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+    }
+    STAMP(6);
+
+    // ---- P6: the observation's cell block (CPP:279-296) + reward weights, slots split over the waves ----
+    const bool rew_on = active && in_flag && n_after > 0;
+    float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+    {
+        const int gb = P.obs_dim - cap * 2;
+        int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * cap : nullptr;
+        if (active) {
+            for (int kb = k0; kb < k1; kb += 4) {                   // 4 slots per round: indices, coordinates, then math + stores
+                int cell[4]; float cx[4], cy[4]; bool have[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? (int)mysel[kb + q] : 0; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = kb + q;
+                    if (k < k1) {
+                        const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
+                        ocol[(size_t)(gb + 2 * k) * n_a] = gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = gy;
+                        if (sdst) sdst[k] = have[q] ? cell[q] : -1;
+                        // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
+                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float psi = have[q] ? 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f) : 0.f;
+                        fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
+                    }
+                }
+            }
+        }
+        if (T > 1) { L.rpart[(sub * 3 + 0) * 64 + l] = fn0; L.rpart[(sub * 3 + 1) * 64 + l] = fn1; L.rpart[(sub * 3 + 2) * 64 + l] = fden; }
+    }
+    STAMP(7);
+    if (T > 1) __syncthreads();
+
+    // ---- P7 (wave 0): reward (CPP:457-564) and per-environment statistics ---------------
+    if (sub == 0) {
+        double reward = 0.0;
+        if (active) {
+            if (T > 1) {
+                fn0 = 0.f; fn1 = 0.f; fden = 0.f;
+#pragma unroll
+                for (int s = 0; s < T; ++s) { fn0 += L.rpart[(s * 3 + 0) * 64 + l]; fn1 += L.rpart[(s * 3 + 1) * 64 + l]; fden += L.rpart[(s * 3 + 2) * 64 + l]; }
+            }
+            bool collision = false;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {                           // CPP:464-496
+                const int j = j6[q];
+                if (j >= 0) {
+                    const double rx = (double)L.px[es * 32 + j] - px, ry = (double)L.py[es * 32 + j] - py;
+                    if (rx * rx + ry * ry < P.T_ravoid) collision = true;   // CPP:487
+                }
+            }
+            bool uniform = false;
+            if (rew_on) {
+                bool known = false;
+                if (fden > 0.f) {
+                    const float v0 = fn0 / fden, v1 = fn1 / fden;
+                    const float vn = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                    if (__builtin_fabsf(vn - 0.05f) > 5e-5f) { uniform = vn < 0.05f; known = true; }
+                }
+                if (!known) {                                       // borderline: the reference's double sums
+                    double num0 = 0.0, num1 = 0.0, den = 0.0;
+                    for (int k = 0; k < n_out; ++k) {
+                        const int cell = mysel[k];
+                        const double gx = (double)gxe[cell] - px, gy = (double)gye[cell] - py;   // CPP:515-516
+                        const double z = sqrt(gx * gx + gy * gy);   // CPP:524
+                        double psi;                                 // CPP:1017-1025, delta = 0
+                        if (z < 0.0 * P.d_sen) psi = 1.0;
+                        else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+                        else psi = 0.0;
+                        num0 += psi * gx; num1 += psi * gy; den += psi;                          // CPP:537-539
+                    }
+                    if (den == 0) den = 1E-8;                       // CPP:542-544
+                    const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;                   // CPP:547-548
+                    uniform = v0 * v0 + v1 * v1 < P.T_v005;         // CPP:550-552
+                }
+            }
+            if (in_flag && !collision && uniform) reward += 1.0;    // CPP:559-561
+            rew_g[(size_t)e * n_a + i] = (float)reward;
+        }
+        STAMP(8);
+        if (P.want_stats) {                                         // TRAIN:128-135; WRAP:48-165
+            const double r = active ? reward : 0.0, m = active ? sqrt(nn_min) : 0.0;
+            const double rs = half_sum(r), rq = half_sum(r * r), ds = half_sum(active ? dmin : 0.0);
+            const double inn = half_sum(active && in_flag ? 1.0 : 0.0), ms = half_sum(m);
+            const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
+            const double mean = ms / n_a, dv = active ? m - mean : 0.0;
+            const double var = half_sum(dv * dv) / n_a;
+            const double cp = half_sum((double)contacts);
+            const double covered = half_sum(i < W ? (double)__popc(cov_e[i]) : 0.0);
+            if (i == 0 && env_ok) {
+                double *st = stats_g + (size_t)e * 8;
+                st[0] += rs; st[1] += rq; st[2] += covered / n_g;
+                st[3] += (var - lo) / (hi - lo);                    // WRAP:98-99
+                st[4] += cp; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+            }
+        }
+    }
+    STAMP(9);
 }
 
 // ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset
@@ -862,6 +1438,29 @@ int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading
     return 0;
 }
 
+template <int T>
+static int launch_step_fast_t(const DevParams &P, float *p, float *dp, const float *act, const float *grid,
+                              const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs,
+                              float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
+{
+    if (int rc = set_lds(k_step_fast<T>, P.fast_lds_bytes)) return rc;
+    hipLaunchKernelGGL(k_step_fast<T>, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, p, dp, act, grid, n_g,
+                       l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, const float *grid, const int *n_g,
+                     const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
+                     int *sensed, int *occupied, double *stats, hipStream_t st)
+{
+    switch (P.fast_T) {
+    case 1: return launch_step_fast_t<1>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    case 2: return launch_step_fast_t<2>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    default: return launch_step_fast_t<4>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    }
+}
+
 template <typename S>
 int launch_step(const DevParams &P, S *p, S *dp, const float *act, const S *grid, const int *n_g,
                 const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
@@ -908,6 +1507,13 @@ int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int
     LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef ASM_DIAG
+int diag_set_buffer(unsigned long long *dev)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &dev, sizeof dev);
+}
+#endif
 
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st)
 {

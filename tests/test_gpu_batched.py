@@ -93,6 +93,53 @@ def test_random_rollout_teacher_forced(torch_cuda, n_a, E, steps, boundary):
     assert np.isfinite(tot)
 
 
+@pytest.mark.parametrize("fast_t", ["0", "1", "2", "4"])
+def test_kernel_schedules_against_oracle(torch_cuda, monkeypatch, fast_t):
+    """The generic kernel (0) and the multi-wave kernel at 1, 2 and 4 waves per workgroup,
+    each checked against the oracle in the packed-inside-the-shape regime."""
+    torch = torch_cuda
+    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E, n_a = 21, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=11, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(4)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy()
+    p = env.p.cpu().numpy()
+    for e in range(0, E, 2):                                  # every other environment packed into its shape
+        p[e] = grid[e][:, rng.choice(n_g[e], n_a, replace=False)] + rng.normal(0, 0.02, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.observe()
+    for t in range(6):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"T={fast_t} step {t}")
+
+
+def test_kernel_schedules_agree_bit_for_bit(torch_cuda, monkeypatch):
+    """Same inputs through the generic kernel and the 1/2/4-wave kernels: identical outputs."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    E, n_a, steps = 301, 30, 12
+    outs = {}
+    for fast_t in ("0", "1", "2", "4"):
+        monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+        env = BatchedAssemblyEnv(E, n_a, seed=3, keep_indices=True)
+        env.reset()
+        rec = []
+        for t in range(steps):
+            obs, rew, _, _, prior = env.step(env.random_actions())
+            rec.append([x.clone() for x in (obs, rew, prior, env.p, env.dp, env.neighbor_index, env.in_flags,
+                                            env.nearest_cell, env.sensed_index, env.occupied_index)])
+        outs[fast_t] = (rec, env.stats.clone())
+    ref, ref_stats = outs["0"]
+    for fast_t in ("1", "2", "4"):
+        rec, st = outs[fast_t]
+        for t in range(steps):
+            for a, b in zip(rec[t], ref[t]):
+                assert torch.equal(a, b), f"T={fast_t} step {t}"
+        assert torch.allclose(st, ref_stats, rtol=1e-5, atol=1e-9)
+
+
 def test_converged_regime_teacher_forced(torch_cuda):
     """Agents packed inside the shape: sensed lists above 80, occupied cells, contacts,
     rewards — the regime random actions rarely reach."""
@@ -233,7 +280,8 @@ def test_stats_match_wrapper_metrics(torch_cuda):
             m = ol.metrics(np.ascontiguousarray(p1[e]), g, env.r_avoid)
             want[e] += [r[e].sum(), (r[e] ** 2).sum(), m["coverage_rate"], m["distribution_uniformity"], contacts[e],
                         m["avg_distance_to_target"], 1.0, env.in_flags[e].sum().item()]
-    np.testing.assert_allclose(env.stats.cpu().numpy(), want, rtol=1e-9, atol=1e-12)
+    # the nearest-neighbour distance of the uniformity metric is picked by an fp32 screen
+    np.testing.assert_allclose(env.stats.cpu().numpy(), want, rtol=1e-5, atol=1e-9)
 
 
 def test_big_swarm_one_step(torch_cuda):

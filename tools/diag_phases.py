@@ -1,0 +1,62 @@
+"""Where a k_step workgroup spends its cycles: runs the DIAGNOSTIC build of the library
+(make -C marl_amd/csrc diag; in-kernel s_memtime stamps) and prints the mean number of
+shader cycles between consecutive stamps.  Read the SHARES, not the totals: the stamps
+cost cycles of their own.
+
+    MARL_AMD_LIB=marl_amd/csrc/build/libAssemblyEnv_diag.so python tools/diag_phases.py [E] [n_a]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("MARL_AMD_LIB", os.path.join(REPO, "marl_amd", "csrc", "build", "libAssemblyEnv_diag.so"))
+import torch  # noqa: E402
+from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+n_a = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+env = BatchedAssemblyEnv(E, n_a)
+lib = env.lib
+env.reset()
+for t in range(30):
+    env.step(env.random_actions())
+grid = 8192
+buf = torch.zeros(grid, 16, dtype=torch.int64, device="cuda")
+assert lib.asm_diag_set_buffer(C.c_void_p(buf.data_ptr())) == 0
+acc = None
+for t in range(10):
+    buf.zero_()
+    env.step(env.random_actions())
+    torch.cuda.synchronize()
+    b = buf.cpu().numpy()
+    b = b[b[:, 9] > 0]
+    d = np.diff(b[:, :10], axis=1).astype(np.float64)
+    acc = d if acc is None else acc + d
+    wall = (b[:, 11] - b[:, 10]).astype(np.float64) / 100.0      # s_memrealtime ticks at 100 MHz
+    span = (b[:, 11].max() - b[:, 10].min()) / 100.0
+lib.asm_diag_set_buffer(None)
+acc /= 10
+q = np.percentile(wall, [50, 90, 99, 100]); st = (b[:, 10] - b[:, 10].min()) / 100.0
+print(f"workgroup lifetime us p50/p90/p99/max = {q[0]:.1f}/{q[1]:.1f}/{q[2]:.1f}/{q[3]:.1f}; start time us p50/p90/max = "
+      f"{np.percentile(st, 50):.1f}/{np.percentile(st, 90):.1f}/{st.max():.1f}")
+if b[:, 12].any():
+    x = b[:, [5, 12, 13, 14, 6]].astype(np.float64)
+    dd = np.diff(x, axis=1)
+    print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f ; slowest P5: %s" % (
+        dd[:, 0].mean(), dd[:, 1].mean(), dd[:, 2].mean(), dd[:, 3].mean(), [[int(v) for v in dd[k]] for k in np.argsort(-dd.sum(1))[:4]]))
+print("ambiguity counters of the 6 slowest-P4 workgroups (1000 per amb_min lane + 1 per amb_sense lane):",
+      [(int(k), int(b[k, 15])) for k in np.argsort(-(b[:, 13] - b[:, 12]))[:6]], "total flagged workgroups", int((b[:, 15] > 0).sum()))
+slow = np.argsort(-wall)[:5]
+print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
+names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
+         "cell pass", "in-flag, popcounts, target block", "sensed emission", "reward", "stats"]
+tot = acc.sum(1).mean()
+print(f"workgroups {acc.shape[0]}, mean cycles per workgroup {tot:.0f}; last launch: mean workgroup lifetime {wall.mean():.1f} us, "
+      f"first start -> last end {span:.1f} us => about {wall.sum() / span / 256:.1f} workgroups resident per CU, "
+      f"clock ~{tot / wall.mean() / 1e3:.2f} GHz")
+for k, n in enumerate(names):
+    print(f"  {n:40s} {acc[:, k].mean():10.0f}  {100 * acc[:, k].mean() / tot:5.1f} %")
