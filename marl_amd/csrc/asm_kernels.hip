@@ -749,8 +749,17 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
     STAMP(0);
 
-    // ---- P0: grid and state into LDS --------------------------------------------------
+    // ---- P0: grid and state into LDS (all global loads issued before the first LDS write) ----
+    const int e0 = blockIdx.x * 2;
+    const int ng0 = e0 < P.E ? ng_g[e0] : 0, ng1 = e0 + 1 < P.E ? ng_g[e0 + 1] : 0;
+    const int n_g = es ? ng1 : ng0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
     {
+        float sa = 1e30f, sb = 1e30f, sc = 0.f, sd = 0.f;
+        if (sub == 0 && active) {
+            const size_t o = (size_t)e * 2 * n_a;
+            sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
+        }
         const int per_env4 = NGP / 2;                               // float4 per environment (2 rows)
         for (int base = 0; base < NGP; base += 64 * T * 4) {
             float4 v[4]; int idx[4];
@@ -759,15 +768,15 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 idx[q] = base + q * 64 * T + tid;
                 v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
                 if (idx[q] < NGP) {
-                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4, eh = blockIdx.x * 2 + h;
-                    if (eh < P.E) v[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)eh * 2 * NGP + (size_t)r * 4);
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
+                    if (e0 + h < P.E) v[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)(e0 + h) * 2 * NGP + (size_t)r * 4);
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (idx[q] < NGP) {
-                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4, eh = blockIdx.x * 2 + h;
-                    const int ngh = eh < P.E ? ng_g[eh] : 0;
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
+                    const int ngh = h ? ng1 : ng0;
                     const int c = r * 4 - (r * 4 >= NGP ? NGP : 0);
                     float4 u = v[q];
                     if (c + 0 >= ngh) u.x = 1e30f;
@@ -779,17 +788,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             }
         }
         for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
-        if (sub == 0) {
-            float a = 1e30f, b = 1e30f, c = 0.f, d = 0.f;
-            if (active) {
-                const size_t o = (size_t)e * 2 * n_a;
-                a = p_g[o + i]; b = p_g[o + n_a + i]; c = dp_g[o + i]; d = dp_g[o + n_a + i];
-            }
-            L.px[l] = a; L.py[l] = b; L.vx[l] = c; L.vy[l] = d;
-        }
+        if (sub == 0) { L.px[l] = sa; L.py[l] = sb; L.vx[l] = sc; L.vy[l] = sd; }
     }
-    const int n_g = env_ok ? ng_g[e] : 1;
-    const double l_cell = env_ok ? lcell_g[e] : 1.0;
     __syncthreads();
     STAMP(1);
 
@@ -942,7 +942,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         unsigned *wkey = reinterpret_cast<unsigned *>(L.sel);       // [64][MW], aliases the slot lists (written later)
         const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
         const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
-        for (int w = sub; w < W; w += T) {
+        // wave 0 also runs the k-NN pass above, so it takes only the first W0 words; the others share the rest
+        const int W0 = T == 1 ? W : (W / T > 3 ? W / T - 3 : 0);
+        for (int w = (T == 1 || sub == 0) ? 0 : W0 + sub - 1; w < ((T == 1 || sub != 0) ? W : W0); w += (T == 1 || sub == 0) ? 1 : T - 1) {
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
             float amb = __builtin_inff();
             const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
@@ -1092,27 +1094,47 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const unsigned two_c = 2u * (unsigned)(cap - 1);
         const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
         const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
-        const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
-        unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
-        int rank = 0, k = k0, w = 0;
         bool busy = active && n_after > 0 && k0 < n_out;
-        while (busy) {
-            if (bits == 0) {
-                if (nz == 0) { busy = false; continue; }
-                w = __ffs(nz) - 1; nz &= nz - 1;
-                bits = mym[w];
-                if (in_flag) bits &= ~occ_e[w];
-                const int pc = __popc(bits);
-                if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+        if (__ballot(busy && n_after > cap) == 0) {
+            // common case: no lane of this wave sub-samples, slot == rank
+            unsigned bits = 0;
+            int rank = 0, w = 0;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0) { busy = false; continue; }
+                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    bits = mym[w];
+                    if (in_flag) bits &= ~occ_e[w];
+                    const int pc = __popc(bits);
+                    if (rank + pc <= k0) { rank += pc; bits = 0; continue; }
+                }
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                if (rank >= k0) mysel[rank] = (unsigned short)(w * 32 + b);
+                ++rank;
+                if (rank >= k1 || rank >= n_out) busy = false;
             }
-            const int b = __ffs(bits) - 1; bits &= bits - 1;
-            if ((unsigned)rank == tq) {
-                mysel[k] = (unsigned short)(w * 32 + b);
-                ++k; tq += inc_q; tr += inc_r;
-                if (tr >= two_c) { tr -= two_c; ++tq; }
-                if (k >= k1 || k >= n_out) busy = false;
+        } else {
+            const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);   // numerator of t_{k0}
+            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
+            int rank = 0, k = k0, w = 0;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0) { busy = false; continue; }
+                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    bits = mym[w];
+                    if (in_flag) bits &= ~occ_e[w];
+                    const int pc = __popc(bits);
+                    if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+                }
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                if ((unsigned)rank == tq) {
+                    mysel[k] = (unsigned short)(w * 32 + b);
+                    ++k; tq += inc_q; tr += inc_r;
+                    if (tr >= two_c) { tr -= two_c; ++tq; }
+                    if (k >= k1 || k >= n_out) busy = false;
+                }
+                ++rank;
             }
-            ++rank;
         }
     }
     if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
@@ -1203,14 +1225,18 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         STAMP(8);
         if (P.want_stats) {                                         // TRAIN:128-135; WRAP:48-165
-            const double r = active ? reward : 0.0, m = active ? sqrt(nn_min) : 0.0;
-            const double rs = half_sum(r), rq = half_sum(r * r), ds = half_sum(active ? dmin : 0.0);
-            const double inn = half_sum(active && in_flag ? 1.0 : 0.0), ms = half_sum(m);
+            const double m = active ? sqrt(nn_min) : 0.0;
+            const unsigned long long half = es ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+            const double rs = (double)__popcll(__ballot(active && reward > 0.0) & half), rq = rs;     // rewards are 0 or 1
+            const double inn = (double)__popcll(__ballot(active && in_flag) & half);
+            int ci = contacts + (i < W ? __popc(cov_e[i]) << 16 : 0);                                 // two small sums in one word
+#pragma unroll
+            for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
+            const double cp = (double)(ci & 0xFFFF), covered = (double)(ci >> 16);
+            const double ds = half_sum(active ? dmin : 0.0), ms = half_sum(m);
             const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
             const double mean = ms / n_a, dv = active ? m - mean : 0.0;
             const double var = half_sum(dv * dv) / n_a;
-            const double cp = half_sum((double)contacts);
-            const double covered = half_sum(i < W ? (double)__popc(cov_e[i]) : 0.0);
             if (i == 0 && env_ok) {
                 double *st = stats_g + (size_t)e * 8;
                 st[0] += rs; st[1] += rq; st[2] += covered / n_g;
