@@ -37,6 +37,20 @@ def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
     return 872.0 + 8.0 * n_g_mean / n_a
 
 
+def measured_traffic(E: int, n_a: int):
+    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json),
+    if they were taken on this workload; None otherwise (counters cannot be read from inside this process)."""
+    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["workload"] == {"envs_per_gpu": E, "agents": n_a}:
+            return t
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 12.0):
     """The CPU path on a bounded sample of the same workload, all host threads we may use."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -154,6 +168,7 @@ def main():
         resets = sum(1 for t in range(W, W + K) if (t + 1) % EPISODE_LENGTH == 0)
         kern_ms = ev_ms / K                                   # k_step launches back to back on one stream
         achieved = E * n_a * b_alg / (kern_ms * 1e-3) / 1e9
+        tr = measured_traffic(E, n_a)
         out = {
             "metric": "agent-steps/sec (whole node) for batched 30-agent assembly envs at 1/2/4/8 GPUs",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -166,8 +181,13 @@ def main():
                        "state": "float32 in HBM; decisions evaluated in float64",
                        "parallelism": f"env-sharded x{world}, RCCL all-reduce of 8 doubles per episode"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step<float>", "avg_launch_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # PMC bytes per launch / this run's launch time, same unit as `achieved`
+                         "traffic": (tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
+                         "traffic_bytes_per_launch": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
+                         "alg_bytes_per_launch": E * n_a * b_alg,
+                         "kernel": "k_step_fast / k_step (asm_batch_step_f32)", "avg_launch_ms": kern_ms,
                          "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": E * n_a},
         }
         if world == 1 and not args.no_cpu_baseline:
