@@ -185,6 +185,11 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
  * kernels rely on it being correctly rounded); n doubles, device pointers. */
 int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream);
 
+/* Self-test hook: *out_max = max(*out_max, max |v_cos_f32(x) - cos(2 pi x)|) over every float x whose
+ * bit pattern lies in [bits_lo, bits_hi] (the hardware cosine takes revolutions).  The single-precision
+ * screen of the reward (CPP:515-552) budgets 5e-7 for it.  out_max: one device double, zeroed by the caller. */
+int asm_debug_cos_f32_max_err(uint32_t bits_lo, uint32_t bits_hi, double *out_max, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

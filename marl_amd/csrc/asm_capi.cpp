@@ -110,7 +110,8 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.Tcontact_hi_f = (float)(P.T_contact * (1.0 + EPS));
     P.inv2dsen_f = (float)(0.5 / P.d_sen);
     // k_step_fast eligibility and geometry (fp32 state only; see asm_kernels.hip)
-    P.capp = (P.n_obs + 7) / 8 * 8;
+    P.capp = P.n_obs + (P.n_obs & 1);                               // even, and an odd number of 32-bit words per
+    if (((P.capp / 2) & 1) == 0) P.capp += 2;                       // agent: no LDS bank conflicts across lanes
     P.fast_T = 0;
     if (state_bytes == 4 && prm->n_a <= 32 && !P.periodic && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
         const int blocks = (E + 1) / 2;
@@ -267,6 +268,13 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
 // diagnostic build only: device buffer [grid][16] of cycle stamps, or NULL to stop stamping
 int asm_diag_set_buffer(void *dev) { return asmenv::diag_set_buffer((unsigned long long *)dev); }
 #endif
+
+int asm_debug_cos_f32_max_err(uint32_t bits_lo, uint32_t bits_hi, double *out_max, void *stream)
+{
+    if (bits_lo > bits_hi || !out_max) return fail(1, "asm_debug_cos_f32_max_err: bad arguments");
+    int rc = asmenv::launch_cos_f32_err(bits_lo, bits_hi, out_max, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_debug_cos_f32_max_err") : 0;
+}
 
 int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream)
 {

@@ -48,6 +48,7 @@ int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, 
                      int *sensed, int *occupied, double *stats, hipStream_t st);
 int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st);
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st);
+int launch_cos_f32_err(uint32_t lo, uint32_t hi, double *out_max, hipStream_t st);
 int launch_reward_compat(const DevParams &P, const double *p, const double *grid, int n_g, const int *nbr,
                          const int *inflags, const int *sensed, bool c_periodic, bool c_interaction,
                          bool c_exploration, double *reward, hipStream_t st);

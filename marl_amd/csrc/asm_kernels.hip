@@ -728,6 +728,14 @@ __device__ __forceinline__ double half_max(double v)
     return v;
 }
 
+// psi(z) of the reward's weighted mean (CPP:1017-1025 with delta = 0), the reference's expression
+__device__ __forceinline__ double reward_weight(const DevParams &P, double z)
+{
+    if (z < 0.0 * P.d_sen) return 1.0;
+    if (z < P.d_sen) return (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+    return 0.0;
+}
+
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
@@ -1013,9 +1021,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         double smin;
         if (active) {
             const bool amb_min = !((G2 >> 5) - (G1 >> 5) >= 2u);
-#ifdef ASM_DIAG
-            if (g_diag && (amb_min || ambw)) atomicAdd(&g_diag[(size_t)blockIdx.x * 16 + 15], amb_min ? 1000ull : 1ull);
-#endif
             if (amb_min) {                                          // words holding a candidate for the minimum
                 const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
                 for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - (G1 >> 5) < 2u) ambw |= 1u << w;
@@ -1068,73 +1073,71 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     __syncthreads();
     STAMP(14);
 
-    // ---- P5: compaction of the sensed lists into LDS, by words --------------------------
+    // ---- P5: compaction of the sensed lists into LDS, words split over the waves ---------
     const unsigned fin = L.fin[l];
     const bool in_flag = (fin >> 31) != 0;
     const unsigned *mym = L.mask + (size_t)l * MW;
     int n_before = 0, n_occ = 0;
-    unsigned nz = 0;                                                // words with a cell that stays in the list
     for (int w = 0; w < W; ++w) {
         const unsigned m = mym[w];
         const unsigned o = in_flag ? m & occ_e[w] : 0u;             // CPP:155: only when inside the shape
         n_before += __popc(m); n_occ += __popc(o);
-        if (m & ~o) nz |= 1u << w;
     }
     const int n_after = active ? n_before - n_occ : 0;
     const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
-    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots
+    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
     {
         // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
         // rank k.  cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double
         // evaluation rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced
         // incrementally as quotient/remainder.  For n <= cap the increment is exactly 1.
-        // One loop per lane over its own set bits (non-empty words only): the wave iterates as often as
-        // its busiest lane needs, not once per word and busiest lane.
-        const unsigned two_c = 2u * (unsigned)(cap - 1);
-        const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
+        // Wave `sub` compacts the words w = sub (mod T): the rank of a word's first bit is the running
+        // popcount, so the waves work independently and only on registers; the wave iterates per word as
+        // often as the fullest word among its lanes needs.
+        const unsigned c1 = (unsigned)(cap - 1), two_c = 2u * c1;
+        const bool samp = n_after > cap;
+        const unsigned num = samp ? 2u * (unsigned)(n_after - 1) : two_c;
         const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
-        bool busy = active && n_after > 0 && k0 < n_out;
-        if (__ballot(busy && n_after > cap) == 0) {
-            // common case: no lane of this wave sub-samples, slot == rank
-            unsigned bits = 0;
-            int rank = 0, w = 0;
-            while (busy) {
-                if (bits == 0) {
-                    if (nz == 0) { busy = false; continue; }
-                    w = __ffs(nz) - 1; nz &= nz - 1;
-                    bits = mym[w];
-                    if (in_flag) bits &= ~occ_e[w];
-                    const int pc = __popc(bits);
-                    if (rank + pc <= k0) { rank += pc; bits = 0; continue; }
+        const bool any_samp = __ballot(samp) != 0;
+        int run = 0;
+        for (int w = 0; w < W; ++w) {
+            unsigned f = mym[w];
+            if (in_flag) f &= ~occ_e[w];
+            if (!active) f = 0;
+            const int pc = __popc(f);
+            if (T == 1 || (w & (T - 1)) == sub) {
+                if (!any_samp) {                                    // common case: slot == rank
+                    int r = run;
+                    while (f) {
+                        const int b = __ffs(f) - 1; f &= f - 1;
+                        mysel[r++] = (unsigned short)(w * 32 + b);
+                    }
+                } else {
+                    unsigned k, tq, tr;                             // first slot whose rank is >= run
+                    if (!samp) { k = (unsigned)run; tq = (unsigned)run; tr = 0; }
+                    else if (run == 0) { k = 0; tq = 0; tr = c1; }
+                    else {
+                        k = (two_c * (unsigned)run - c1 + num - 1u) / num;      // t_k >= run  <=>  k*num + c1 >= 2*c1*run
+                        const unsigned n0 = k * num + c1;
+                        tq = n0 / two_c; tr = n0 - tq * two_c;
+                    }
+                    const unsigned end = (unsigned)(run + pc);
+                    if (tq >= end || k >= (unsigned)cap) f = 0;
+                    unsigned r = (unsigned)run;
+                    while (f) {
+                        const int b = __ffs(f) - 1; f &= f - 1;
+                        if (r == tq) {
+                            mysel[k] = (unsigned short)(w * 32 + b);
+                            ++k; tq += inc_q; tr += inc_r;
+                            if (tr >= two_c) { tr -= two_c; ++tq; }
+                            if (tq >= end || k >= (unsigned)cap) f = 0;
+                        }
+                        ++r;
+                    }
                 }
-                const int b = __ffs(bits) - 1; bits &= bits - 1;
-                if (rank >= k0) mysel[rank] = (unsigned short)(w * 32 + b);
-                ++rank;
-                if (rank >= k1 || rank >= n_out) busy = false;
             }
-        } else {
-            const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);   // numerator of t_{k0}
-            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
-            int rank = 0, k = k0, w = 0;
-            while (busy) {
-                if (bits == 0) {
-                    if (nz == 0) { busy = false; continue; }
-                    w = __ffs(nz) - 1; nz &= nz - 1;
-                    bits = mym[w];
-                    if (in_flag) bits &= ~occ_e[w];
-                    const int pc = __popc(bits);
-                    if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
-                }
-                const int b = __ffs(bits) - 1; bits &= bits - 1;
-                if ((unsigned)rank == tq) {
-                    mysel[k] = (unsigned short)(w * 32 + b);
-                    ++k; tq += inc_q; tr += inc_r;
-                    if (tr >= two_c) { tr -= two_c; ++tq; }
-                    if (k >= k1 || k >= n_out) busy = false;
-                }
-                ++rank;
-            }
+            run += pc;
         }
     }
     if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
@@ -1143,6 +1146,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         emit_list(it, in_flag ? n_occ : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
     }
     STAMP(6);
+    if (T > 1) __syncthreads();                                     // the lists are complete
+    STAMP(15);
 
     // ---- P6: the observation's cell block (CPP:279-296) + reward weights, slots split over the waves ----
     const bool rew_on = active && in_flag && n_after > 0;
@@ -1150,15 +1155,16 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     {
         const int gb = P.obs_dim - cap * 2;
         int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * cap : nullptr;
+        constexpr int RB = 10;                                      // slots per round: indices, coordinates, then math + stores
         if (active) {
-            for (int kb = k0; kb < k1; kb += 4) {                   // 4 slots per round: indices, coordinates, then math + stores
-                int cell[4]; float cx[4], cy[4]; bool have[4];
+            for (int kb = k0; kb < k1; kb += RB) {
+                int cell[RB]; float cx[RB], cy[RB]; bool have[RB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? (int)mysel[kb + q] : 0; }
+                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? (int)mysel[kb + q] : 0; }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
+                for (int q = 0; q < RB; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < RB; ++q) {
                     const int k = kb + q;
                     if (k < k1) {
                         const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
@@ -1180,13 +1186,13 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // ---- P7 (wave 0): reward (CPP:457-564) and per-environment statistics ---------------
     if (sub == 0) {
         double reward = 0.0;
+        bool collision = false, uniform = false, known = true;      // known: the reward's uniformity test is decided
         if (active) {
             if (T > 1) {
                 fn0 = 0.f; fn1 = 0.f; fden = 0.f;
 #pragma unroll
                 for (int s = 0; s < T; ++s) { fn0 += L.rpart[(s * 3 + 0) * 64 + l]; fn1 += L.rpart[(s * 3 + 1) * 64 + l]; fden += L.rpart[(s * 3 + 2) * 64 + l]; }
             }
-            bool collision = false;
 #pragma unroll
             for (int q = 0; q < 6; ++q) {                           // CPP:464-496
                 const int j = j6[q];
@@ -1195,31 +1201,64 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     if (rx * rx + ry * ry < P.T_ravoid) collision = true;   // CPP:487
                 }
             }
-            bool uniform = false;
             if (rew_on) {
-                bool known = false;
+                known = false;
                 if (fden > 0.f) {
-                    const float v0 = fn0 / fden, v1 = fn1 / fden;
+                    // Single-precision screen.  The weights psi carry an absolute error below 1e-6 (argument
+                    // rounding 2*pi*1.5e-7, v_cos_f32 below 5e-7, halved, plus one rounding), every term and
+                    // every accumulation step a relative rounding of 6e-8, so with n terms and |g| < d_sen
+                    // |v32 - v| < 0.64 n (1e-6 / den + 6e-8) + 1e-7 for the norm v of the mean offset; doubled here.
+                    const float rden = 1.0f / fden;
+                    const float v0 = fn0 * rden, v1 = fn1 * rden;
                     const float vn = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
-                    if (__builtin_fabsf(vn - 0.05f) > 5e-5f) { uniform = vn < 0.05f; known = true; }
-                }
-                if (!known) {                                       // borderline: the reference's double sums
-                    double num0 = 0.0, num1 = 0.0, den = 0.0;
-                    for (int k = 0; k < n_out; ++k) {
-                        const int cell = mysel[k];
-                        const double gx = (double)gxe[cell] - px, gy = (double)gye[cell] - py;   // CPP:515-516
-                        const double z = sqrt(gx * gx + gy * gy);   // CPP:524
-                        double psi;                                 // CPP:1017-1025, delta = 0
-                        if (z < 0.0 * P.d_sen) psi = 1.0;
-                        else if (z < P.d_sen) psi = (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
-                        else psi = 0.0;
-                        num0 += psi * gx; num1 += psi * gy; den += psi;                          // CPP:537-539
-                    }
-                    if (den == 0) den = 1E-8;                       // CPP:542-544
-                    const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;                   // CPP:547-548
-                    uniform = v0 * v0 + v1 * v1 < P.T_v005;         // CPP:550-552
+                    const float margin = 1.28f * (float)n_out * __builtin_fmaf(1e-6f, rden, 6e-8f) + 2e-7f;
+                    if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; known = true; }
                 }
             }
+        }
+        // Borderline agents: the reference's double-precision sums (CPP:515-552), one agent at a time with the
+        // 64 lanes sharing its slots.  The terms are the reference's; only their order of summation differs
+        // (relative error below 80 * 2^-53), so a result within 1e-11 of the threshold falls through to the
+        // sequential evaluation in the reference's order.
+        for (unsigned long long todo = __ballot(!known); todo; todo &= todo - 1) {
+            const int src = __ffsll(todo) - 1;
+            const int n_src = __builtin_amdgcn_readlane(n_out, src);
+            const double sx = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pxf), src));
+            const double sy = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pyf), src));
+            const unsigned short *ssel = L.sel + (size_t)src * P.capp;
+            const float *sgx = L.g + (size_t)(src >> 5) * 2 * NGP, *sgy = sgx + NGP;
+            double num0 = 0.0, num1 = 0.0, den = 0.0;
+            for (int k = l; k < n_src; k += 64) {
+                const int cell = ssel[k];
+                const double gx = (double)sgx[cell] - sx, gy = (double)sgy[cell] - sy;           // CPP:515-516
+                const double psi = reward_weight(P, sqrt(gx * gx + gy * gy));                     // CPP:524
+                num0 += psi * gx; num1 += psi * gy; den += psi;                                  // CPP:537-539
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                num0 += __shfl_xor(num0, m, 64); num1 += __shfl_xor(num1, m, 64); den += __shfl_xor(den, m, 64);
+            }
+            if (l == src) {
+                if (den == 0) den = 1E-8;                           // CPP:542-544
+                const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;                       // CPP:547-548
+                const double q = v0 * v0 + v1 * v1;
+                if (fabs(q - P.T_v005) > 1e-11 * P.T_v005) {
+                    uniform = q < P.T_v005;                         // CPP:550-552
+                } else {
+                    num0 = 0.0; num1 = 0.0; den = 0.0;
+                    for (int k = 0; k < n_out; ++k) {
+                        const int cell = mysel[k];
+                        const double gx = (double)gxe[cell] - px, gy = (double)gye[cell] - py;
+                        const double psi = reward_weight(P, sqrt(gx * gx + gy * gy));
+                        num0 += psi * gx; num1 += psi * gy; den += psi;
+                    }
+                    if (den == 0) den = 1E-8;
+                    const double w0 = 1.0 * num0 / den, w1 = 1.0 * num1 / den;
+                    uniform = w0 * w0 + w1 * w1 < P.T_v005;
+                }
+            }
+        }
+        if (active) {
             if (in_flag && !collision && uniform) reward += 1.0;    // CPP:559-561
             rew_g[(size_t)e * n_a + i] = (float)reward;
         }
@@ -1331,6 +1370,21 @@ __global__ void k_sqrt_f64(const double *in, double *out, int n)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = sqrt(in[k]);
+}
+
+// max over the float bit patterns [lo, hi] of |v_cos_f32(x) - cos(2 pi x)| (v_cos_f32 takes revolutions)
+__global__ void k_cos_f32_err(uint32_t lo, uint32_t hi, unsigned long long *out)
+{
+    double worst = 0.0;
+    for (uint64_t b = (uint64_t)lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= (uint64_t)hi;
+         b += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)b);
+        const double err = fabs((double)__builtin_amdgcn_cosf(x) - cos(2.0 * ASM_PI * (double)x));
+        worst = fmax(worst, err);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) worst = fmax(worst, __shfl_xor(worst, m, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(worst));   // non-negative doubles order like integers
 }
 
 // ---- the three small reference-compatible kernels (double, one environment) ----
@@ -1540,6 +1594,14 @@ int diag_set_buffer(unsigned long long *dev)
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &dev, sizeof dev);
 }
 #endif
+
+int launch_cos_f32_err(uint32_t lo, uint32_t hi, double *out_max, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)hi - lo + 1;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_cos_f32_err, dim3(blocks), dim3(256), 0, st, lo, hi, reinterpret_cast<unsigned long long *>(out_max));
+    return (int)hipGetLastError();
+}
 
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st)
 {

@@ -45,6 +45,22 @@ def test_device_sqrt_f64_is_correctly_rounded(torch_cuda):
     assert np.array_equal(out.cpu().numpy(), np.sqrt(x))
 
 
+def test_device_cos_f32_error_budget(torch_cuda):
+    """The reward's single-precision screen budgets 5e-7 for v_cos_f32 on [0, 0.5] revolutions
+    (z / (2 d_sen) with z < d_sen); checked here over every float of that interval."""
+    torch = torch_cuda
+    import ctypes as C
+    from marl_amd import _lib
+    lib = _lib.load()
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    lo, hi = 0, int(np.float32(0.5).view(np.uint32))
+    _lib.check(lib.asm_debug_cos_f32_max_err(lo, hi, C.c_void_p(out.data_ptr()), None), "cos")
+    torch.cuda.synchronize()
+    err = float(out.item())
+    print("max |v_cos_f32 - cos| on [0, 0.5] rev:", err)
+    assert 0.0 < err < 5e-7
+
+
 @pytest.mark.parametrize("path", ROLLOUTS, ids=[os.path.basename(p)[8:-4] for p in ROLLOUTS])
 def test_golden_states_observe_and_step(torch_cuda, path):
     """Every recorded reference state, rounded to the fp32 state the device holds:

@@ -43,13 +43,15 @@ acc /= 10
 q = np.percentile(wall, [50, 90, 99, 100]); st = (b[:, 10] - b[:, 10].min()) / 100.0
 print(f"workgroup lifetime us p50/p90/p99/max = {q[0]:.1f}/{q[1]:.1f}/{q[2]:.1f}/{q[3]:.1f}; start time us p50/p90/max = "
       f"{np.percentile(st, 50):.1f}/{np.percentile(st, 90):.1f}/{st.max():.1f}")
+h, _ = np.histogram(st, bins=np.arange(0, max(st.max(), 1.0) + 4.0, 4.0))
+print("workgroup starts per 4 us:", h.tolist())
+e_ = (b[:, 11] - b[:, 10].min()) / 100.0
+h, _ = np.histogram(e_, bins=np.arange(0, max(e_.max(), 1.0) + 4.0, 4.0))
+print("workgroup ends per 4 us:  ", h.tolist())
 if b[:, 12].any():
-    x = b[:, [5, 12, 13, 14, 6]].astype(np.float64)
+    x = b[:, [5, 12, 13, 14, 6, 15, 7]].astype(np.float64)
     dd = np.diff(x, axis=1)
-    print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f ; slowest P5: %s" % (
-        dd[:, 0].mean(), dd[:, 1].mean(), dd[:, 2].mean(), dd[:, 3].mean(), [[int(v) for v in dd[k]] for k in np.argsort(-dd.sum(1))[:4]]))
-print("ambiguity counters of the 6 slowest-P4 workgroups (1000 per amb_min lane + 1 per amb_sense lane):",
-      [(int(k), int(b[k, 15])) for k in np.argsort(-(b[:, 13] - b[:, 12]))[:6]], "total flagged workgroups", int((b[:, 15] > 0).sum()))
+    print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f | barrier %.0f | emission %.0f" % tuple(dd.mean(0)))
 slow = np.argsort(-wall)[:5]
 print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
 names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
