@@ -265,7 +265,7 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
 }
 
 #ifdef ASM_DIAG
-// diagnostic build only: device buffer [grid][16] of cycle stamps, or NULL to stop stamping
+// diagnostic build only: device buffer [grid][32] of cycle stamps, or NULL to stop stamping
 int asm_diag_set_buffer(void *dev) { return asmenv::diag_set_buffer((unsigned long long *)dev); }
 #endif
 

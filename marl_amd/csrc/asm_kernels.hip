@@ -32,11 +32,13 @@ namespace asmenv {
 // Diagnostic build only (make diag): cycle stamps at phase boundaries, written by lane 0
 // of each workgroup's first wave to a buffer of its own.  The product build has no stamps.
 #ifdef ASM_DIAG
-__device__ unsigned long long *g_diag = nullptr;          // [grid][16]
-#define STAMP(k) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
-    if ((k) == 0) g_diag[(size_t)blockIdx.x * 16 + 10] = wall_clock64(); if ((k) == 9) g_diag[(size_t)blockIdx.x * 16 + 11] = wall_clock64(); } } while (0)
+__device__ unsigned long long *g_diag = nullptr;          // [grid][32]
+#define DIAG_COUNT(k, v) do { if (g_diag && threadIdx.x == 0) g_diag[(size_t)blockIdx.x * 32 + (k)] = (unsigned long long)(v); } while (0)
+#define STAMP(k) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
+    if ((k) == 0) g_diag[(size_t)blockIdx.x * 32 + 10] = wall_clock64(); if ((k) == 9) g_diag[(size_t)blockIdx.x * 32 + 11] = wall_clock64(); } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define DIAG_COUNT(k, v) do { } while (0)
 #endif
 
 __device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double hh)
@@ -1073,77 +1075,115 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     __syncthreads();
     STAMP(14);
 
-    // ---- P5: compaction of the sensed lists into LDS, words split over the waves ---------
+    // ---- P5: compaction of the sensed lists into LDS -----------------------------------
     const unsigned fin = L.fin[l];
     const bool in_flag = (fin >> 31) != 0;
     const unsigned *mym = L.mask + (size_t)l * MW;
-    int n_before = 0, n_occ = 0;
+    const unsigned inm = in_flag ? 0xFFFFFFFFu : 0u;                // CPP:155: occupied cells drop out only inside the shape
+    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
+    int n_after = 0, wst = 0, bst = 0;
+    unsigned nz = 0;                                                // words with a cell that stays in the list
+    bool found = false;
     for (int w = 0; w < W; ++w) {
-        const unsigned m = mym[w];
-        const unsigned o = in_flag ? m & occ_e[w] : 0u;             // CPP:155: only when inside the shape
-        n_before += __popc(m); n_occ += __popc(o);
+        unsigned f = mym[w] & ~(occ_e[w] & inm);
+        if (!active) f = 0;
+        const int pc = __popc(f);
+        if (pc && !found && n_after >= k0) { wst = w; bst = n_after; found = true; }   // first word whose ranks start at or after k0
+        if (pc) nz |= 1u << w;
+        n_after += pc;
     }
-    const int n_after = active ? n_before - n_occ : 0;
     const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
-    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
+    STAMP(16);
+    [[maybe_unused]] int diag_it = 0;
     {
         // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
-        // rank k.  cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double
-        // evaluation rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced
-        // incrementally as quotient/remainder.  For n <= cap the increment is exactly 1.
-        // Wave `sub` compacts the words w = sub (mod T): the rank of a word's first bit is the running
-        // popcount, so the waves work independently and only on registers; the wave iterates per word as
-        // often as the fullest word among its lanes needs.
-        const unsigned c1 = (unsigned)(cap - 1), two_c = 2u * c1;
-        const bool samp = n_after > cap;
-        const unsigned num = samp ? 2u * (unsigned)(n_after - 1) : two_c;
-        const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
-        const bool any_samp = __ballot(samp) != 0;
-        int run = 0;
-        for (int w = 0; w < W; ++w) {
-            unsigned f = mym[w];
-            if (in_flag) f &= ~occ_e[w];
-            if (!active) f = 0;
-            const int pc = __popc(f);
-            if (T == 1 || (w & (T - 1)) == sub) {
-                if (!any_samp) {                                    // common case: slot == rank
-                    int r = run;
-                    while (f) {
-                        const int b = __ffs(f) - 1; f &= f - 1;
-                        mysel[r++] = (unsigned short)(w * 32 + b);
-                    }
-                } else {
-                    unsigned k, tq, tr;                             // first slot whose rank is >= run
-                    if (!samp) { k = (unsigned)run; tq = (unsigned)run; tr = 0; }
-                    else if (run == 0) { k = 0; tq = 0; tr = c1; }
-                    else {
-                        k = (two_c * (unsigned)run - c1 + num - 1u) / num;      // t_k >= run  <=>  k*num + c1 >= 2*c1*run
-                        const unsigned n0 = k * num + c1;
-                        tq = n0 / two_c; tr = n0 - tq * two_c;
-                    }
-                    const unsigned end = (unsigned)(run + pc);
-                    if (tq >= end || k >= (unsigned)cap) f = 0;
-                    unsigned r = (unsigned)run;
-                    while (f) {
-                        const int b = __ffs(f) - 1; f &= f - 1;
-                        if (r == tq) {
-                            mysel[k] = (unsigned short)(w * 32 + b);
-                            ++k; tq += inc_q; tr += inc_r;
-                            if (tr >= two_c) { tr -= two_c; ++tq; }
-                            if (tq >= end || k >= (unsigned)cap) f = 0;
-                        }
-                        ++r;
-                    }
+        // rank k.  One loop per lane over its own set bits; the wave iterates as often as its busiest lane.
+        if (__ballot(n_after > cap) == 0) {
+            // Common case, no lane of the workgroup sub-samples: slot == rank.  Wave `sub` lists the words
+            // whose first rank lies in [k0, k1) (found above, so it starts without skipping anything).  The
+            // lane's next QN non-empty words are fetched into registers in one batch, so the loop below runs
+            // without waiting on LDS; a lane that needs more words finishes in the second loop.
+            constexpr int QN = 6;
+            bool busy = found && bst < k1;
+            int rank = bst;
+            nz &= 0xFFFFFFFFu << wst;
+            unsigned fq[QN], wq = 0;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const bool has = nz != 0;
+                const int wi = has ? __ffs(nz) - 1 : 0;
+                nz &= nz - 1;                                       // stays 0 once empty
+                const unsigned f = mym[wi] & ~(occ_e[wi] & inm);
+                fq[q] = has ? f : 0u;
+                wq |= (unsigned)wi << (5 * q);
+            }
+            unsigned bits = fq[0];
+            while (busy) {
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                mysel[rank++] = (unsigned short)((wq & 31u) * 32 + b);
+                ++diag_it;
+                if (bits == 0) {
+#pragma unroll
+                    for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
+                    fq[QN - 1] = 0; wq >>= 5;
+                    bits = fq[0];
+                    if (bits == 0 || rank >= k1) busy = false;
                 }
             }
-            run += pc;
+            busy = found && rank < k1 && nz != 0;                   // rare: more than QN words in this wave's range
+            bits = 0;
+            int w = 0;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0 || rank >= k1) { busy = false; continue; }
+                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    bits = mym[w] & ~(occ_e[w] & inm);
+                }
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                mysel[rank++] = (unsigned short)(w * 32 + b);
+            }
+#ifdef ASM_DIAG
+            for (int m = 32; m >= 1; m >>= 1) diag_it = max(diag_it, __shfl_xor(diag_it, m, 64));
+            DIAG_COUNT(17, diag_it);
+#endif
+        } else {
+            DIAG_COUNT(18, 1);
+            // cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double evaluation
+            // rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced incrementally
+            // as quotient/remainder (increment exactly 1 for n <= cap).  Wave `sub` fills the slots [k0, k1).
+            const unsigned two_c = 2u * (unsigned)(cap - 1);
+            const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
+            const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
+            const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
+            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
+            int rank = 0, k = k0, w = 0;
+            bool busy = active && k0 < n_out;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0) { busy = false; continue; }
+                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    bits = mym[w] & ~(occ_e[w] & inm);
+                    const int pc = __popc(bits);
+                    if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+                }
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                if ((unsigned)rank == tq) {
+                    mysel[k] = (unsigned short)(w * 32 + b);
+                    ++k; tq += inc_q; tr += inc_r;
+                    if (tr >= two_c) { tr -= two_c; ++tq; }
+                    if (k >= k1 || k >= n_out) busy = false;
+                }
+                ++rank;
+            }
         }
     }
     if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
         int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
+        int n_occ_list = 0;
+        for (int w = 0; w < W; ++w) n_occ_list += __popc(mym[w] & occ_e[w]);
         BitIter it; it.init(mym, W, occ_e, false);
-        emit_list(it, in_flag ? n_occ : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+        emit_list(it, in_flag ? n_occ_list : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
     }
     STAMP(6);
     if (T > 1) __syncthreads();                                     // the lists are complete
@@ -1168,7 +1208,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     const int k = kb + q;
                     if (k < k1) {
                         const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
+#ifndef ASM_EXP_NOSTORE
                         ocol[(size_t)(gb + 2 * k) * n_a] = gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = gy;
+#endif
                         if (sdst) sdst[k] = have[q] ? cell[q] : -1;
                         // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
                         const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));

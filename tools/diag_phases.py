@@ -25,7 +25,7 @@ env.reset()
 for t in range(30):
     env.step(env.random_actions())
 grid = 8192
-buf = torch.zeros(grid, 16, dtype=torch.int64, device="cuda")
+buf = torch.zeros(grid, 32, dtype=torch.int64, device="cuda")
 assert lib.asm_diag_set_buffer(C.c_void_p(buf.data_ptr())) == 0
 acc = None
 for t in range(10):
@@ -52,6 +52,13 @@ if b[:, 12].any():
     x = b[:, [5, 12, 13, 14, 6, 15, 7]].astype(np.float64)
     dd = np.diff(x, axis=1)
     print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f | barrier %.0f | emission %.0f" % tuple(dd.mean(0)))
+    if b[:, 16].any():
+        print("P5 split: popcount pass %.0f | list loop %.0f cycles, %.1f iterations of thread 0 (max %d)" % (
+            (b[:, 16] - b[:, 14]).mean(), (b[:, 6] - b[:, 16]).mean(), b[:, 17].mean(), b[:, 17].max()))
+        ss = b[:, 18] > 0
+        ll = (b[:, 6] - b[:, 16]).astype(np.float64)
+        print("workgroups with a sub-sampling lane: %d of %d; list loop cycles %.0f with, %.0f without (%.1f iterations)" % (
+            int(ss.sum()), b.shape[0], ll[ss].mean() if ss.any() else 0, ll[~ss].mean(), b[~ss, 17].mean()))
 slow = np.argsort(-wall)[:5]
 print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
 names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
