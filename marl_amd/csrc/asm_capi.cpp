@@ -115,7 +115,8 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.fast_T = 0;
     if (state_bytes == 4 && prm->n_a <= 32 && !P.periodic && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
         const int blocks = (E + 1) / 2;
-        int T = blocks <= 2048 ? 4 : (blocks <= 4096 ? 2 : 1);       // enough waves to fill 256 CUs
+        (void)blocks;
+        int T = 4;                                                   // fastest measured schedule at every batch size from 2048 to 32768 environments
         if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
         if (T == 1 || T == 2 || T == 4) {
             const size_t bytes = 4 * (256 + 4 * (size_t)P.NGP + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
