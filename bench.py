@@ -38,9 +38,9 @@ def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
 
 
 def measured_traffic(E: int, n_a: int):
-    """HBM bytes per k_step launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json),
+    """HBM bytes per k_step launch and VALU busy from the committed rocprofv3 PMC passes (profiles/r01_pmc.json),
     if they were taken on this workload; None otherwise (counters cannot be read from inside this process)."""
-    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    path = os.path.join(REPO, "profiles", "r01_pmc.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -185,7 +185,10 @@ def main():
                          # PMC bytes per launch / this run's launch time, same unit as `achieved`
                          "traffic": (tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
                          "traffic_bytes_per_launch": tr["hbm_bytes_per_launch"] if tr else None,
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
+                         "traffic_source": "profiles/r01_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
+                         # rocprof's VALUBusy formula on the same PMC passes: the kernel is bound by instruction
+                         # issue, not by bandwidth
+                         "valu_busy": tr.get("valu_busy") if tr else None,
                          "alg_bytes_per_launch": E * n_a * b_alg,
                          "kernel": "k_step_fast / k_step (asm_batch_step_f32)", "avg_launch_ms": kern_ms,
                          "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": E * n_a},
