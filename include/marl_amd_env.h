@@ -181,6 +181,30 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
 int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a,
                                  float *act, void *stream);
 
+/* ---- Group C: on-device replay of batched rollouts ------------------------------------------
+ * Counterpart of ReplayBufferAgent (marl_llm/algorithm/utils/buffer_agent.py:21-177) for the batched
+ * environment.  Storage is caller-owned device memory, organised by episode slots of `episode_length`
+ * steps so that the step kernel's own outputs are the stored rows (obs is written once and serves as
+ * next_obs of the previous step, buffer_agent.py:107-110):
+ *   obs_ring   [slots][episode_length + 1][E][obs_dim][n_a]   frame t = observation before step t
+ *   act_ring   [slots][episode_length][E][2][n_a]             actions (train_assembly.py:121-125)
+ *   prior_ring [slots][episode_length][E][2][n_a]             a_prior of the step (nullable)
+ *   rew_ring   [slots][episode_length][E][n_a]                rewards
+ * A transition id is ((slot * episode_length + t) * E + e) * n_a + i.  Rows come out agent-major like
+ * buffer_agent.py:157-177: obs_out/next_obs_out [N][obs_dim], act_out/prior_out [N][2], rew_out [N].
+ * done is all zeros in this environment (assembly.py:475-477) and is not stored. */
+int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const float *obs_ring,
+                          const float *act_ring, const float *prior_ring /*nullable*/, const float *rew_ring,
+                          const int64_t *index /*[N], device*/, int N, float *obs_out, float *act_out,
+                          float *rew_out, float *next_obs_out, float *prior_out /*nullable*/, void *stream);
+
+/* index[k] = lo + floor(u_k * (hi - lo)) with u_k from the counter-based generator (key = seed,
+ * counter = (k, counter), stream 2): uniform transition ids WITH replacement (buffer_agent.py:149-154
+ * draws without replacement; with >= 1e7 stored rows and 2048 draws the difference is ~2e-4 expected
+ * duplicates per batch). */
+int asm_replay_draw_indices(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N,
+                            int64_t *index, void *stream);
+
 /* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the
  * kernels rely on it being correctly rounded); n doubles, device pointers. */
 int asm_debug_sqrt_f64(const double *in, double *out, int n, void *stream);

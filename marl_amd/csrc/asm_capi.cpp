@@ -265,6 +265,25 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
     return rc ? hip_fail(rc, "asm_batch_random_actions_f32") : 0;
 }
 
+int asm_replay_draw_indices(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *index, void *stream)
+{
+    if (N < 1 || hi <= lo || !index) return fail(1, "asm_replay_draw_indices: bad arguments");
+    int rc = asmenv::launch_replay_draw(seed, counter, lo, hi, N, index, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_replay_draw_indices") : 0;
+}
+
+int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const float *obs_ring, const float *act_ring,
+                          const float *prior_ring, const float *rew_ring, const int64_t *index, int N, float *obs_out,
+                          float *act_out, float *rew_out, float *next_obs_out, float *prior_out, void *stream)
+{
+    if (E < 1 || n_a < 1 || obs_dim < 1 || episode_length < 1 || N < 1 || !obs_ring || !act_ring || !rew_ring || !index ||
+        !obs_out || !act_out || !rew_out || !next_obs_out || (prior_out && !prior_ring))
+        return fail(1, "asm_replay_gather_f32: bad arguments");
+    int rc = asmenv::launch_replay_gather(E, n_a, obs_dim, episode_length, obs_ring, act_ring, prior_ring, rew_ring, index, N,
+                                          obs_out, act_out, rew_out, next_obs_out, prior_out, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_replay_gather_f32") : 0;
+}
+
 #ifdef ASM_DIAG
 // diagnostic build only: device buffer [grid][32] of cycle stamps, or NULL to stop stamping
 int asm_diag_set_buffer(void *dev) { return asmenv::diag_set_buffer((unsigned long long *)dev); }

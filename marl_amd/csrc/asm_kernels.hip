@@ -1408,6 +1408,45 @@ __global__ void k_random_actions(uint64_t seed, uint32_t step, int64_t env0, int
     act[idx] = (float)(-1.0 + 2.0 * u);                                          // ENV:519
 }
 
+// ---- replay: uniform transition ids and the gather of sampled transitions ----------------
+// out[k] = lo + floor(u * (hi - lo)), u from two 32-bit draws of counter stream 2
+__global__ void k_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint64_t u = ((uint64_t)draw_u32(seed, (uint64_t)k, counter, 2u, 0u) << 32) | draw_u32(seed, (uint64_t)k, counter, 2u, 1u);
+    out[k] = lo + (int64_t)__umul64hi(u, (uint64_t)(hi - lo));
+}
+
+// One wavefront per sampled transition id = ((slot * T + t) * E + e) * n_a + i.  The observation of step t is
+// frame t of the episode slot and the next observation is frame t + 1 of the same slot, so an observation
+// is stored once.  An agent's observation is a column of the (obs_dim, n_a) frame: obs_dim strided reads,
+// one contiguous row written.
+__global__ void k_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ring, const float *act_ring,
+                                const float *prior_ring, const float *rew_ring, const int64_t *index, int N,
+                                float *obs_out, float *act_out, float *rew_out, float *next_out, float *prior_out)
+{
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= N) return;
+    const int64_t id = index[k];
+    const int i = (int)(id % n_a);
+    const int64_t q = id / n_a;                                     // (slot * T + t) * E + e
+    const int e = (int)(q % E);
+    const int64_t st = q / E, slot = st / T, t = st - slot * T;
+    const size_t frame = (size_t)obs_dim * n_a;
+    const float *o = obs_ring + ((size_t)(slot * (T + 1) + t) * E + e) * frame + i;
+    const float *o2 = o + (size_t)E * frame;
+    for (int r = lane; r < obs_dim; r += 64) {
+        obs_out[(size_t)k * obs_dim + r] = o[(size_t)r * n_a];
+        next_out[(size_t)k * obs_dim + r] = o2[(size_t)r * n_a];
+    }
+    if (lane < 2) {
+        act_out[(size_t)k * 2 + lane] = act_ring[((size_t)q * 2 + lane) * n_a + i];
+        if (prior_out) prior_out[(size_t)k * 2 + lane] = prior_ring[((size_t)q * 2 + lane) * n_a + i];
+    }
+    if (lane == 2) rew_out[k] = rew_ring[(size_t)q * n_a + i];
+}
+
 __global__ void k_sqrt_f64(const double *in, double *out, int n)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1626,6 +1665,23 @@ int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int
 {
     const size_t n = (size_t)E * 2 * n_a;
     hipLaunchKernelGGL(k_random_actions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, step, env0, E, n_a, act);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_replay_draw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, seed, counter, lo, hi, N, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ring, const float *act_ring,
+                         const float *prior_ring, const float *rew_ring, const int64_t *index, int N, float *obs_out,
+                         float *act_out, float *rew_out, float *next_out, float *prior_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, E, n_a, obs_dim, T, obs_ring,
+                       act_ring, prior_ring, rew_ring, index, N, obs_out, act_out, rew_out, next_out, prior_out);
     LAUNCH_CHECK();
     return 0;
 }

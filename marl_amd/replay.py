@@ -1,0 +1,201 @@
+"""Replay storage for the assembly environments.
+
+Two classes:
+
+* ``ReplayBufferAgent`` — the reference's host-side buffer
+  (marl_llm/algorithm/utils/buffer_agent.py:13-198) restated over torch tensors on any device,
+  same constructor, ``push``/``sample``/``get_average_rewards`` signatures and the same quirks
+  (tail overwrite instead of wrap-around, sampling window that ignores the fill level).  It lets
+  train_assembly.py:83-155 run unchanged against the single-environment mirror.
+
+* ``DeviceReplay`` — the batched counterpart: episode slots in HBM into which the step kernel
+  writes observations, rewards and priors directly (no push copy; an observation is stored once
+  and serves as next_obs of the previous step), and a HIP gather kernel that returns
+  agent-major batches like buffer_agent.py:157-177.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class ReplayBufferAgent:
+    """buffer_agent.py:13-198 with torch storage (float64 like the numpy original by default)."""
+
+    BEGIN_INDEX_RANGE = 300000                                  # buffer_agent.py:145
+
+    def __init__(self, max_steps, num_agents, start_stop_index, state_dim, action_dim, device="cpu",
+                 dtype=torch.float64):
+        self.max_steps = max_steps
+        self.num_agents = num_agents
+        self.total_length = self.max_steps * self.num_agents       # buffer_agent.py:45
+        z = lambda d: torch.zeros(self.total_length, d, dtype=dtype, device=device)
+        self.obs_buffs = z(state_dim)
+        self.ac_buffs = z(action_dim)
+        self.ac_prior_buffs = z(action_dim)
+        self.log_pi_buffs = z(1)
+        self.rew_buffs = z(1)
+        self.next_obs_buffs = z(state_dim)
+        self.done_buffs = z(1)
+        self.filled_i = 0
+        self.curr_i = 0
+        self.agent_index = start_stop_index
+        self.device = torch.device(device)
+        self.dtype = dtype
+
+    def __len__(self):
+        return self.filled_i
+
+    def _rows(self, x, index):
+        """x[:, index].T as a tensor of the storage dtype on the storage device."""
+        t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+        return t[:, index].T.to(device=self.device, dtype=self.dtype)
+
+    def push(self, observations_orig, actions_orig, rewards_orig, next_observations_orig, dones_orig, index,
+             actions_prior_orig=None, log_pi_orig=None):
+        """buffer_agent.py:67-128."""
+        data_length = len(range(index.start, index.stop))
+        if self.curr_i + data_length > self.total_length:          # buffer_agent.py:102-104: overwrite the tail
+            rollover = data_length - (self.total_length - self.curr_i)
+            self.curr_i -= rollover
+        sl = slice(self.curr_i, self.curr_i + data_length)
+        self.obs_buffs[sl] = self._rows(observations_orig, index)
+        self.ac_buffs[sl] = self._rows(actions_orig, index)
+        self.rew_buffs[sl] = self._rows(rewards_orig, index)
+        self.next_obs_buffs[sl] = self._rows(next_observations_orig, index)
+        self.done_buffs[sl] = self._rows(dones_orig, index)
+        if actions_prior_orig is not None:
+            self.ac_prior_buffs[sl] = self._rows(actions_prior_orig, index)
+        if log_pi_orig is not None:
+            self.log_pi_buffs[sl] = self._rows(log_pi_orig, index)
+        self.curr_i += data_length
+        if self.filled_i < self.total_length:                      # buffer_agent.py:123-124
+            self.filled_i += data_length
+        if self.curr_i == self.total_length:
+            self.curr_i = 0
+
+    def sample(self, N, to_gpu=False, is_prior=False, is_log_pi=False):
+        """buffer_agent.py:130-177.  Index draws use numpy's global generator like the original, so a
+        seeded run picks the same rows.  Returns float32 tensors (torch.Tensor(...) in the original)."""
+        begin_index = np.random.randint(0, self.BEGIN_INDEX_RANGE)
+        inds = np.random.choice(
+            np.arange(begin_index, self.total_length - self.BEGIN_INDEX_RANGE + begin_index, dtype=np.int32),
+            size=N, replace=False)
+        idx = torch.from_numpy(inds.astype(np.int64)).to(self.device)
+        dev = torch.device("cuda") if to_gpu else torch.device("cpu")
+        cast = lambda b: b[idx].to(device=dev, dtype=torch.float32).requires_grad_(False)
+        return (cast(self.obs_buffs), cast(self.ac_buffs), cast(self.rew_buffs), cast(self.next_obs_buffs),
+                cast(self.done_buffs), cast(self.ac_prior_buffs) if is_prior else None,
+                cast(self.log_pi_buffs) if is_log_pi else None)
+
+    def get_average_rewards(self, N):
+        """buffer_agent.py:179-198 (rows, not agents, are indexed by the original; kept as is)."""
+        if self.filled_i == self.max_steps:
+            inds = np.arange(self.curr_i - N, self.curr_i)
+        else:
+            inds = np.arange(max(0, self.curr_i - N), self.curr_i)
+        r = self.rew_buffs.cpu().numpy()
+        return [r[i][inds].mean() for i in range(self.num_agents)]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class DeviceReplay:
+    """Episode slots in HBM for a BatchedAssemblyEnv.
+
+        replay = DeviceReplay(env, episode_length=200, slots=4)
+        replay.begin_episode(); obs = env.reset()
+        for t in range(200):
+            a = replay.action_slot()            # (E, 2, n_a) tensor to fill with the policy's actions
+            ...; env.step(a); replay.advance()
+        batch = replay.sample(2048)             # obs, act, rew, next_obs, done, a_prior
+
+    begin_episode() and advance() point the environment's obs / reward / a_prior outputs at the next
+    frame of the current slot, so stepping is the push (train_assembly.py:123-125 without the copy).
+    Sample between episodes, as train_assembly.py:141-157 does: while an episode is being written into a
+    reused slot, the transition at the write front pairs a new observation with an old next one.
+    """
+
+    def __init__(self, env, episode_length: int, slots: int, seed: int = 0):
+        self.env = env
+        self.lib = _lib.load()
+        self.T, self.S = int(episode_length), int(slots)
+        E, n, d, dev = env.E, env.n_a, env.obs_dim_agent, env.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.obs_ring = torch.zeros(self.S, self.T + 1, E, d, n, **f32)
+        self.act_ring = torch.zeros(self.S, self.T, E, 2, n, **f32)
+        self.prior_ring = torch.zeros(self.S, self.T, E, 2, n, **f32) if env.training_method == "llm_rl" else None
+        self.rew_ring = torch.zeros(self.S, self.T, E, 1, n, **f32)
+        self.slot, self.t = -1, 0
+        self.filled_slots = 0                                       # completed episodes available to sample()
+        self.seed, self.draws = int(seed), 0
+
+    # ---- writing ---------------------------------------------------------------------
+    def begin_episode(self) -> None:
+        """Call before env.reset(): the reset's observation becomes frame 0 of the next slot."""
+        self.slot = (self.slot + 1) % self.S
+        self.t = 0
+        self.env.obs = self.obs_ring[self.slot, 0]
+
+    def action_slot(self) -> torch.Tensor:
+        """Where this step's actions are stored; pass it to env.step() after filling it."""
+        self._point_outputs()
+        return self.act_ring[self.slot, self.t]
+
+    def _point_outputs(self) -> None:
+        e = self.env
+        e.obs = self.obs_ring[self.slot, self.t + 1]
+        e.reward = self.rew_ring[self.slot, self.t]
+        if self.prior_ring is not None:
+            e.a_prior = self.prior_ring[self.slot, self.t]
+
+    def advance(self) -> None:
+        """Call after env.step()."""
+        self.t += 1
+        if self.t == self.T:                                        # slots fill in order, then are reused in order
+            self.filled_slots = min(self.S, self.filled_slots + 1)
+
+    def __len__(self) -> int:
+        """Stored transitions (agent rows), as len(ReplayBufferAgent)."""
+        return self.filled_slots * self.T * self.env.E * self.env.n_a
+
+    # ---- sampling --------------------------------------------------------------------
+    def draw_indices(self, N: int) -> torch.Tensor:
+        if len(self) == 0:
+            raise RuntimeError("no completed episode to sample from")
+        idx = torch.empty(N, dtype=torch.int64, device=self.env.device)
+        with torch.cuda.device(self.env.device):
+            rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, 0, len(self), N, _ptr(idx), self.env._stream())
+        _lib.check(rc, "asm_replay_draw_indices")
+        self.draws += 1
+        return idx
+
+    def gather(self, idx: torch.Tensor, is_prior: bool = True):
+        """Rows of the transitions idx (int64 ids on the device): the tuple of buffer_agent.py:175-177
+        without log_pi: (obs, act, rew, next_obs, done, a_prior)."""
+        e = self.env
+        if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.device != self.obs_ring.device:
+            raise ValueError("idx must be a contiguous int64 tensor on the environment's device")
+        N, d = idx.numel(), e.obs_dim_agent
+        f32 = dict(dtype=torch.float32, device=e.device)
+        obs, nxt = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+        act, rew = torch.empty(N, 2, **f32), torch.empty(N, 1, **f32)
+        want_prior = is_prior and self.prior_ring is not None
+        pri = torch.empty(N, 2, **f32) if want_prior else None
+        with torch.cuda.device(e.device):
+            rc = self.lib.asm_replay_gather_f32(e.E, e.n_a, d, self.T, _ptr(self.obs_ring), _ptr(self.act_ring),
+                                                _ptr(self.prior_ring), _ptr(self.rew_ring), _ptr(idx), N, _ptr(obs),
+                                                _ptr(act), _ptr(rew), _ptr(nxt), _ptr(pri), e._stream())
+        _lib.check(rc, "asm_replay_gather_f32")
+        done = torch.zeros(N, 1, **f32)                             # assembly.py:475-477: never done
+        return obs, act, rew, nxt, done, pri
+
+    def sample(self, N: int, is_prior: bool = True):
+        return self.gather(self.draw_indices(N), is_prior)

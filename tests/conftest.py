@@ -18,3 +18,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
