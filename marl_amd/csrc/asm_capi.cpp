@@ -78,7 +78,8 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.NGP = (prm->n_g_max + 31) / 32 * 32;
     P.W = P.NGP / 32;
     P.MW = (P.W | 1) < 9 ? 9 : (P.W | 1);
-    size_t env_bytes = state_bytes * (4 * (size_t)P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.SL * P.MW + 2 * (size_t)P.W);
+    size_t env_bytes = state_bytes * (4 * (size_t)P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.SL * P.MW + 2 * (size_t)P.W) +
+                       2 * (size_t)P.SL * P.MW;                          // + 16-bit word keys of the large-swarm cell pass
     env_bytes = (env_bytes + 15) / 16 * 16;
     P.lds_env_bytes = (unsigned)env_bytes;
     P.lds_block_bytes = (unsigned)(env_bytes * P.EPB);

@@ -73,11 +73,14 @@ __device__ __forceinline__ double draw_uniform(uint64_t seed, uint64_t env, uint
     return lo + (hi - lo) * u;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ---- LDS carve ------------------------------------------------------------------
 template <typename S>
 struct EnvLds {
     S *px, *py, *vx, *vy, *gx, *gy;
     unsigned *mask, *occ, *cov;
+    unsigned short *wkey;          // [SL][MW] upper half of the smallest key of every word (large-swarm cell pass)
 };
 
 template <typename S>
@@ -90,6 +93,7 @@ __device__ __forceinline__ EnvLds<S> carve(unsigned char *base, const DevParams 
     L.gx = f + 4 * P.SL; L.gy = L.gx + P.NGP;
     unsigned *u = reinterpret_cast<unsigned *>(L.gy + P.NGP);
     L.mask = u; L.occ = u + (size_t)P.SL * P.MW; L.cov = L.occ + P.W;
+    L.wkey = reinterpret_cast<unsigned short *>(L.cov + P.W);
     return L;
 }
 
@@ -178,6 +182,111 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     unsigned r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// Bit b of the result: fl32 |(X[b], Y[b]) - (px, py)|^2 < thr, b = 0..31 (X, Y 16-byte aligned in LDS).
+__device__ __forceinline__ unsigned pair_screen32(const float *X, const float *Y, float px, float py, float thr)
+{
+    unsigned m = 0;
+    const f32x2 p2x = {px, px}, p2y = {py, py};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 x4 = reinterpret_cast<const float4 *>(X)[q], y4 = reinterpret_cast<const float4 *>(Y)[q];
+        const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+        const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+        const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa), sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sa.x - thr), 31);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sa.y - thr), 31);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sb.x - thr), 31);
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(sb.y - thr), 31);
+    }
+    return __brev(m);
+}
+
+// The agent x cell pass of one agent over all W words with single-precision screening and exact
+// settlement of whatever the screen cannot decide, word by word (same scheme as k_step_fast below,
+// one lane doing all the words): sensed mask, occupancy/coverage bits, nearest cell (first minimum).
+__device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, float pxf, float pyf, const float *gx,
+                                               const float *gy, unsigned *mw, unsigned short *wkey, unsigned *occ,
+                                               unsigned *cov)
+{
+    const double px = pxf, py = pyf;
+    unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;
+    const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+    const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
+    for (int w = 0; w < P.W; ++w) {
+        unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
+        float amb = __builtin_inff();
+        const float4 *X = reinterpret_cast<const float4 *>(gx + w * 32);
+        const float4 *Y = reinterpret_cast<const float4 *>(gy + w * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 x4 = X[q], y4 = Y[q];
+            const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+            const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+            const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+            const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+            const float ss[4] = {sa.x, sa.y, sb.x, sb.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sv = ss[r];
+                const unsigned key = (__float_as_uint(sv) & ~31u) | (unsigned)(q * 4 + r);
+                k2 = umed3(k1, k2, key);
+                k1 = k1 < key ? k1 : key;
+                const f32x2 s2 = {sv, sv};
+                const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half_hi)
+                word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
+                ocand = __builtin_amdgcn_alignbit(ocand, __float_as_uint(d.y), 31);
+                amb = __builtin_fminf(amb, __builtin_fabsf(d.x));
+            }
+        }
+        mw[w] = __brev(word);
+        wkey[w] = (unsigned short)(k1 >> 16);
+        if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
+        ocand = active ? __brev(ocand) : 0u;
+        while (ocand) {                                                     // rare: exact occupancy / coverage test
+            const int b = __ffs(ocand) - 1; ocand &= ocand - 1;
+            const double rxd = (double)gx[w * 32 + b] - px, ryd = (double)gy[w * 32 + b] - py;
+            const double sd = rxd * rxd + ryd * ryd;
+            if (sd < P.T_half_le) {                                         // CPP:190  !(norm > r_avoid/2)
+                atomicOr(&occ[w], 1u << b);
+                if (sd < P.T_half_lt) atomicOr(&cov[w], 1u << b);           // WRAP:67
+            }
+        }
+        if (k1 < G1) G1w = (unsigned)w;
+        const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
+        G2 = m < t ? m : t;
+        G1 = G1 < k1 ? G1 : k1;
+    }
+    int imin = (int)(G1w * 32 + (G1 & 31u));
+    const bool amb_min = !((G2 >> 5) - (G1 >> 5) >= 2u);
+    if (amb_min)                                                            // words holding a candidate for the minimum
+        for (int w = 0; w < P.W; ++w) if ((unsigned)wkey[w] - (G1 >> 16) < 2u) ambw |= 1u << w;
+    if (ambw) {
+        double best = __builtin_inf(); int besti = imin;
+        const unsigned lo = G1 >> 5;
+        while (ambw) {
+            const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
+            unsigned word = mw[w];
+#pragma unroll 4
+            for (int b = 0; b < 32; ++b) {
+                const int c = w * 32 + b;
+                const float rx = gx[c] - pxf, ry = gy[c] - pyf;
+                const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+                const bool a = __builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f;
+                const bool m = amb_min && ((__float_as_uint(s32) >> 5) - lo < 2u);
+                if (a || m) {
+                    const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
+                    const double sd = dx * dx + dy * dy;
+                    if (a) { if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b); }
+                    if (m && sd < best) { best = sd; besti = c; }           // ascending index + strict '<': first minimum
+                }
+            }
+            mw[w] = word;
+        }
+        if (amb_min) imin = besti;
+    }
+    return imin;
 }
 
 // Single-precision screening pass over the cells for one agent (fp32 state only).
@@ -276,6 +385,8 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
 {
     constexpr bool F32 = sizeof(S) == 4;
     const int n_a = P.n_a;
+    // large swarms on fp32 state: pair loops screen 32 agents at a time, the cell pass settles undecided words only
+    const bool swarm = F32 && !P.periodic && P.SL >= 64;
     const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
     const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
     S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
@@ -292,7 +403,29 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             for (int q = 0; q < 6; ++q)
                 if (ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
         };
-        if (F32 && !P.periodic) {
+        if (swarm) {
+            if constexpr (F32) {
+                const float pxf = L.px[i], pyf = L.py[i];
+                for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                    unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
+                    if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));        // self removed CPP:677-681
+                    while (m) {                                                 // ascending j: ties keep the lower index
+                        const int j = j0 + __ffs(m) - 1; m &= m - 1;
+                        const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                        const double s = dx * dx + dy * dy;                     // CPP:641
+                        if (s < P.T_sen) consider(j, s);                        // CPP:663
+                    }
+                }
+                if (P.want_stats) {                                             // nearest other agent (WRAP:81-99)
+                    if (s6[0] > 0.0 && j6[0] >= 0) nn_min = s6[0];
+                    else
+                        for (int j = 0; j < n_a; ++j) {
+                            const double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py, su = rx * rx + ry * ry;
+                            if (su != 0 && su < nn_min) nn_min = su;
+                        }
+                }
+            }
+        } else if (F32 && !P.periodic) {
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
             float nn32 = __builtin_inff(); int nnj = -1;
             for (int j = 0; j < n_a; ++j) {
@@ -348,8 +481,13 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     if (active) {
         bool done = false;
         if constexpr (F32) {
-            done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
-                                  reinterpret_cast<const float *>(L.gy), i, L.mask, L.occ, L.cov, imin);
+            if (swarm) {
+                imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW,
+                                       L.wkey + (size_t)i * P.MW, L.occ, L.cov);
+                done = true;
+            } else
+                done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
+                                      reinterpret_cast<const float *>(L.gy), i, L.mask, L.occ, L.cov, imin);
             if (done) { const double rx = (double)L.gx[imin] - px, ry = (double)L.gy[imin] - py; smin = rx * rx + ry * ry; }
         }
         if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
@@ -486,7 +624,44 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             scr[(size_t)i * 4 + 2] = dmin;   scr[(size_t)i * 4 + 3] = in_flag ? 1.0 : 0.0;
         }
         __syncthreads();
-        if (i == 0 && e < P.E) {
+        if (swarm) {
+            // whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials
+            const int wave = i >> 6, nw = P.SL >> 6;
+            double *part = scr + (size_t)4 * P.SL;                           // [nw][8] behind the per-agent values
+            double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0,
+                           active ? sqrt(nn_min) : 0.0, active ? sqrt(nn_min) : __builtin_inf(),
+                           active ? sqrt(nn_min) : -__builtin_inf(), 0.0};
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
+                v[3] += __shfl_xor(v[3], m, 64);
+                v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
+            }
+            if ((i & 63) == 0) for (int q = 0; q < 6; ++q) part[wave * 8 + q] = v[q];
+            __syncthreads();
+            double ms = 0;
+            for (int w = 0; w < nw; ++w) ms += part[w * 8 + 3];
+            const double mean = ms / n_a, dv = active ? sqrt(nn_min) - mean : 0.0;
+            double sq = dv * dv;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+            if ((i & 63) == 0) part[wave * 8 + 6] = sq;
+            __syncthreads();
+            if (i == 0 && e < P.E) {
+                double rs = 0, ds = 0, inn = 0, var = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+                for (int w = 0; w < nw; ++w) {
+                    rs += part[w * 8]; ds += part[w * 8 + 1]; inn += part[w * 8 + 2]; var += part[w * 8 + 6];
+                    lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
+                }
+                var /= n_a;
+                int covered = 0;
+                for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
+                double *st = stats_g + (size_t)e * 8;
+                st[0] += rs; st[1] += rs; st[2] += (double)covered / P.n_g_e;   // rewards are 0 or 1
+                st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
+                st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+            }
+        } else if (i == 0 && e < P.E) {
             double rs = 0, rq = 0, ds = 0, inn = 0, ms = 0, lo = __builtin_inf(), hi = -__builtin_inf();
             for (int a = 0; a < n_a; ++a) {
                 double r = scr[(size_t)a * 4], m = scr[(size_t)a * 4 + 1];
@@ -524,6 +699,8 @@ __device__ __forceinline__ void load_env(const DevParams &P, const EnvLds<S> &L,
         const size_t b = (size_t)e * 2 * P.n_a;
         L.px[i] = p_g[b + i]; L.py[i] = p_g[b + P.n_a + i];
         L.vx[i] = dp_g[b + i]; L.vy[i] = dp_g[b + P.n_a + i];
+    } else {                                                                 // unused slots: far away, so the chunked
+        L.px[i] = (S)1e30; L.py[i] = (S)1e30; L.vx[i] = (S)0; L.vy[i] = (S)0;   // pair screens never select them
     }
 }
 
@@ -570,6 +747,26 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
         const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
         // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
         double fx = 0.0, fy = 0.0;
+        if (sizeof(S) == 4 && !P.periodic && P.SL >= 64) {                       // large swarm: 32 agents per screen
+            if constexpr (sizeof(S) == 4) {
+                const float pxf = L.px[i], pyf = L.py[i];
+                for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                    unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tcontact_hi_f);
+                    if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
+                    while (m) {                                                  // ascending k, CPP:740-820
+                        const int k = j0 + __ffs(m) - 1; m &= m - 1;
+                        const double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;
+                        const double s = dx * dx + dy * dy;
+                        if (s < P.T_contact) {
+                            const double d = sqrt(s), gap = fabs(d - P.sizes2);
+                            fx += 1.0 * gap * P.k_ball * (-(dx / d));
+                            fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                            if (k > i) ++contacts;
+                        }
+                    }
+                }
+            }
+        } else
         for (int k = 0; k < n_a; ++k) {
             if (k == i) continue;
             if (sizeof(S) == 4) {                                                // fp32 screen: certain misses
@@ -682,8 +879,6 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
 //   * pair loops (contacts, k-NN) screen all 32 candidates in fp32 into a bit mask and run the
 //     exact double evaluation only on the set bits.
 // T is chosen by the host so that a launch has enough waves to fill the chip.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 struct FastLds {
     float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
     float *g;                      // [2][2][NGP]  per env: x row, y row; cells >= n_g hold 1e30
@@ -1387,6 +1582,8 @@ __global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t en
             L.px[i] = a; L.py[i] = b; L.vx[i] = c; L.vy[i] = dd;
             const size_t o = (size_t)e * 2 * n_a;
             p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = dd;
+        } else {
+            L.px[i] = (S)1e30; L.py[i] = (S)1e30; L.vx[i] = (S)0; L.vy[i] = (S)0;
         }
     } else {
         for (int c = i; c < P.NGP; c += P.SL) { L.gx[c] = (S)1e30; L.gy[c] = (S)1e30; }
