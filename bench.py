@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--agents", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-indices", action="store_true", help="also materialise sensed/occupied index lists")
+    ap.add_argument("--regime", choices=["random", "packed"], default="random",
+                    help="random: the reference's reset (ENV:197-210), most agents outside the shape; packed: every "
+                         "agent starts on a cell of its shape (the converged regime: full sensing, occupancy filter, sub-sampling)")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +126,17 @@ def main():
 
     E, n_a, K, W = args.envs_per_gpu, args.agents, args.steps, args.warmup
     env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0], keep_indices=args.keep_indices)
-    env.reset(episode=0)
+
+    def reset_env(episode=None):
+        env.reset(episode=episode)
+        if args.regime == "packed":                           # agents onto random cells of their own shape, + 2 cm jitter
+            g = torch.Generator(device=device).manual_seed(1000 + env.episode)
+            cell = (torch.rand(E, n_a, device=device, generator=g) * env.n_g[:, None]).long().clamp_(max=env.n_g_max - 1)
+            pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a))
+            env.p.copy_(pos + 0.02 * torch.randn(E, 2, n_a, device=device, generator=g))
+            env.observe()
+
+    reset_env(episode=0)
     ring = min(max(K, 1), 64)
     actions = torch.empty(ring, E, 2, n_a, dtype=torch.float32, device=device)
     for k in range(ring):
@@ -141,7 +154,7 @@ def main():
             env.step(actions[t % ring])
             if (t + 1) % EPISODE_LENGTH == 0:               # end of episode (TRAIN:99,107,177-197)
                 totals.add_(reduce_episode_stats(env.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
-                env.reset()
+                reset_env()
 
     # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
@@ -175,7 +188,8 @@ def main():
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{E} parallel assembly envs x {n_a} agents per GPU, random U(-1,1) actions "
-                                   f"(configs[1] of BASELINE.json), 7 reference shapes, walls on, llm_rl prior on",
+                                   f"(configs[1] of BASELINE.json), 7 reference shapes, walls on, llm_rl prior on"
+                                   + (", agents started inside their shapes" if args.regime == "packed" else ""),
                        "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
                        "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,
                        "state": "float32 in HBM; decisions evaluated in float64",

@@ -933,6 +933,9 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
     return 0.0;
 }
 
+#ifndef ASM_W0_LESS
+#define ASM_W0_LESS 2        // words wave 0 gives up in the cell pass because it also runs the k-NN pass
+#endif
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
@@ -1148,7 +1151,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
         const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
         // wave 0 also runs the k-NN pass above, so it takes only the first W0 words; the others share the rest
-        const int W0 = T == 1 ? W : (W / T > 3 ? W / T - 3 : 0);
+        const int W0 = T == 1 ? W : (W / T > ASM_W0_LESS ? W / T - ASM_W0_LESS : 0);
         for (int w = (T == 1 || sub == 0) ? 0 : W0 + sub - 1; w < ((T == 1 || sub != 0) ? W : W0); w += (T == 1 || sub == 0) ? 1 : T - 1) {
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
             float amb = __builtin_inff();
