@@ -118,12 +118,27 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
+    # Rehearsal knobs for a one-GPU box: MARL_AMD_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # MARL_AMD_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Not for measurements.
+    if os.environ.get("MARL_AMD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("MARL_AMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    trace = os.environ.get("MARL_AMD_BENCH_TRACE") == "1"
+
+    def mark(what):
+        if trace:
+            print(f"[bench rank {rank}] {what}", file=sys.stderr, flush=True)
+
+    mark("process group ready")
     E, n_a, K, W = args.envs_per_gpu, args.agents, args.steps, args.warmup
     env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0], keep_indices=args.keep_indices)
 
@@ -158,15 +173,20 @@ def main():
 
     # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
+    mark("environment reset, actions drawn")
     run_steps(W)
+    mark("warm-up steps done")
     totals.add_(reduce_episode_stats(env.episode_stats())).zero_()
+    mark("warm-up all-reduce done")
     barrier()
+    mark("barrier passed, timing")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     run_steps(K, W)
     ev1.record()
     barrier()
+    mark("timed region done")
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
