@@ -232,10 +232,16 @@ class AssemblySwarmEnv(Env):
                 pass
             elif self.agent_strategy == "random":
                 a = np.random.uniform(-1, 1, (self.act_dim_agent, self.n_a))             # ENV:519
+            elif self.agent_strategy == "llm":                                           # ENV:520-524
+                a = np.zeros((self.dim, self.n_a))
+                for i in range(self.n_a):
+                    a[:, i] = self.robot_prior_policy(i, self._get_trgt_grid_state(i)[1])
+            elif self.agent_strategy == "rule":                                          # ENV:525-596
+                a = np.zeros((self.dim, self.n_a))
+                for i in range(self.n_a):
+                    a[:, i] = self._rule_action(i)
             else:
-                raise NotImplementedError(
-                    f"agent_strategy={self.agent_strategy!r}: only 'input' and 'random' are implemented "
-                    "(the 'rule' and 'llm' Python strategies of ENV:520-596 are outside this build's step path)")
+                print("Wrong in Step function")                                          # ENV:597-598
             a_prior = None
             if self.training_method == "llm_rl":
                 a_prior = np.zeros((self.dim, self.n_a))
@@ -266,6 +272,79 @@ class AssemblySwarmEnv(Env):
 
     def render(self, mode="human"):
         raise NotImplementedError("rendering (ENV:663-752, matplotlib) is not part of this build")
+
+    # ------------------------------------------------------------------ in-environment policies
+    def _get_trgt_grid_state(self, self_id):
+        """ENV:833-849: in-shape flag, target position/velocity and the cells inside the sensing range."""
+        norms = np.linalg.norm(self.grid_center - self.p[:, [self_id]], axis=0)
+        nearest = np.argmin(norms)
+        sensed = np.where(norms < self.d_sen)[0]
+        if norms[nearest] < np.sqrt(2) * self.l_cell / 2:
+            return 1, self.p[:, self_id], self.dp[:, self_id], sensed
+        return 0, self.grid_center[:, nearest], np.array([0, 0]), sensed
+
+    def _rho_cos_dec(self, z, delta, r):
+        """ENV:867-870."""
+        z = np.asarray(z)
+        return np.where(z < delta * r, 1.0, np.where(z < r, 0.5 * (1.0 + np.cos(np.pi * (z / r - delta) / (1.0 - delta))), 0.0))
+
+    def robot_prior_policy(self, robot_id, target_position):
+        """ENV:897-944: attraction to the target, repulsion from listed neighbours closer than r_avoid,
+        velocity synchronisation with the listed neighbours, clipped to [-1, 1]."""
+        pos, vel = self.p[:, robot_id], self.dp[:, robot_id]
+        force = np.array([0.0, 0.0])
+        to_target = target_position - pos
+        dist = np.linalg.norm(to_target)
+        force += 2.0 * to_target / dist if dist > 0 else np.array([0.0, 0.0])
+        nbrs = self.neighbor_index[robot_id]
+        nbrs = nbrs[nbrs != -1]
+        vels = []
+        for j in nbrs:
+            away = pos - self.p[:, j]
+            d = np.linalg.norm(away)
+            vels.append(self.dp[:, j])
+            if 0 < d < self.r_avoid:
+                force += 1.0 * (self.r_avoid / d - 1) * (away / d)
+        if vels:
+            force += 2.0 * (np.mean(vels, axis=0) - vel)
+        return np.clip(force, -1, 1)
+
+    def _rule_action(self, i):
+        """ENV:528-594 for agent i: entering + exploration + interaction velocities, clipped."""
+        k_1, k_2, k_3 = 1, 15, 17
+        in_flag, t_pos, t_vel, sensed = self._get_trgt_grid_state(i)
+        to_t = t_pos - self.p[:, i]
+        v_ent = np.zeros(self.dim) if in_flag == 1 else \
+            k_1 * (to_t / (np.linalg.norm(to_t) + 1e-8)) + (t_vel - self.dp[:, i])
+        rel = self.p - self.p[:, [i]]
+        rel_norm = np.linalg.norm(rel, axis=0)
+        if len(sensed) > 0 and in_flag == 1:                           # drop the cells some nearby agent occupies
+            cells = self.grid_center[:, sensed]
+            for j in np.where(rel_norm < (self.d_sen + self.r_avoid / 2))[0]:
+                keep = np.where(np.linalg.norm(cells - self.p[:, [j]], axis=0) > self.r_avoid / 2)[0]
+                cells = cells[:, keep]
+                sensed = sensed[keep]
+        n = len(sensed)
+        if n > self.num_obs_grid_max:                                  # ENV:560-565
+            pick = np.round(np.arange(0, self.num_obs_grid_max) * ((n - 1) / (self.num_obs_grid_max - 1))).astype(int)
+            sensed = np.array(sensed)[pick]
+        v_exp = np.zeros(self.dim)
+        if n > 0:
+            g = self.grid_center[:, sensed] - self.p[:, [i]]
+            psi = self._rho_cos_dec(np.linalg.norm(g, axis=0), 0, self.d_sen)
+            den = np.sum(psi)
+            if den == 0:
+                den = 1e-8
+            v_exp += k_2 * np.sum(psi * g, axis=1) / den
+        v_int = np.zeros(self.dim)
+        near = np.where(rel_norm < self.d_sen)[0]
+        near = near[near != i]
+        vel_rel = self.dp - self.dp[:, [i]]
+        for j in near:
+            if rel_norm[j] < self.r_avoid:
+                v_int += -k_3 * (self.r_avoid / rel_norm[j] - 1) * rel[:, j]
+            v_int += 5 * vel_rel[:, j] / len(near)
+        return np.clip(v_ent + v_exp + v_int, -1, 1)
 
     # ------------------------------------------------------------------ helpers
     def _make_periodic(self, x, is_rel):

@@ -54,3 +54,17 @@ def test_reset_draw_order_matches_reference_ranges():
     e = env.env
     assert obs.shape == (192, e.n_a) and e.d_sen == 0.4 and np.array_equal(e.boundary_pos, [-2.4, 2.4, 2.4, -2.4])
     assert np.abs(e.p).max() <= 2.4 and np.abs(e.dp).max() <= 0.5 and e.n_g in (497, 487, 534, 516, 510, 502, 536)
+
+
+@pytest.mark.parametrize("name", ["rule", "llm"])
+def test_in_environment_policies_follow_the_reference(name):
+    """agent_strategy 'rule' / 'llm' (assembly.py:520-596): the environment steps itself; the recorded
+    reference trajectory (tests/golden/strategy_*.npz) is reproduced bit for bit."""
+    z = np.load(os.path.join(GOLDEN, f"strategy_{name}.npz"))
+    env = _make(z); e = env.env
+    e.agent_strategy = name
+    e._get_obs()
+    for t in range(z["p"].shape[0]):
+        obs, rew, _, _, _ = env.step(np.zeros((2, e.n_a), np.float32))
+        for key, got in (("p", e.p), ("dp", e.dp), ("obs", obs), ("rew", rew), ("in_flags", e.in_flags)):
+            assert np.array_equal(got, z[key][t]), f"{key} differs at step {t}"
