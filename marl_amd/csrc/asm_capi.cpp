@@ -108,6 +108,8 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.Tsen_amb_f = (float)(EPS * P.T_sen);
     P.Tsen_hi_f = (float)(P.T_sen * (1.0 + EPS));
     P.Thalf_hi_f = (float)(P.T_half_le * (1.0 + EPS));
+    P.Thalf_f = (float)P.T_half_le;                                 // decided in fp32 unless within Thalf_amb_f of it
+    P.Thalf_amb_f = (float)(EPS * P.T_half_le);
     P.Tcontact_hi_f = (float)(P.T_contact * (1.0 + EPS));
     P.inv2dsen_f = (float)(0.5 / P.d_sen);
     // k_step_fast eligibility and geometry (fp32 state only; see asm_kernels.hip)

@@ -26,7 +26,7 @@ struct DevParams {
     double T_contact;               // norm - 2*size_a < 0     ENV:445-446
     double T_v005;                  // norm < 0.05             CPP:552
     // single-precision screens (S = float): threshold, margins, inflated thresholds
-    float Tsen_f, Tsen_amb_f, Tsen_hi_f, Thalf_hi_f, Tcontact_hi_f, inv2dsen_f;
+    float Tsen_f, Tsen_amb_f, Tsen_hi_f, Thalf_hi_f, Thalf_f, Thalf_amb_f, Tcontact_hi_f, inv2dsen_f;
     double d_sen, r_avoid, sizes2, size_a, vel_max, k_ball, k_wall, c_wall, dt, sens, mass, half_w, half_h;
 };
 

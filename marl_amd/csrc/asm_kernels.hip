@@ -203,6 +203,35 @@ __device__ __forceinline__ unsigned pair_screen32(const float *X, const float *Y
     return __brev(m);
 }
 
+// Occupancy (CPP:190, !(norm > r_avoid/2)) and coverage (WRAP:67, norm < r_avoid/2) bits of one agent for
+// one 32-cell word, OR-ed into the environment's bitmaps.  `oc` is the single-precision screen s32 < T_half;
+// it is exact for both tests unless some cell lies within the margin of the threshold (smallest |s32 - T_half|
+// in `ambo`), in which case this agent settles the whole word in double.
+__device__ __forceinline__ void settle_occupancy(const DevParams &P, bool active, unsigned oc, float ambo, double px,
+                                                 double py, const float *gx, const float *gy, unsigned *occ_w,
+                                                 unsigned *cov_w)
+{
+    if (!active) oc = 0;
+    const bool undecided = active && !(ambo > P.Thalf_amb_f);
+    if (__ballot(undecided)) {                                              // rare
+        if (undecided) {
+            oc = 0;
+            unsigned cv = 0;
+#pragma nounroll
+            for (int b = 0; b < 32; ++b) {
+                const double rxd = (double)gx[b] - px, ryd = (double)gy[b] - py;
+                const double sd = rxd * rxd + ryd * ryd;
+                if (sd < P.T_half_le) oc |= 1u << b;
+                if (sd < P.T_half_lt) cv |= 1u << b;
+            }
+            if (cv) atomicOr(cov_w, cv);
+            if (oc) atomicOr(occ_w, oc);
+            oc = 0;
+        }
+    }
+    if (oc) { atomicOr(occ_w, oc); atomicOr(cov_w, oc); }
+}
+
 // The agent x cell pass of one agent over all W words with single-precision screening and exact
 // settlement of whatever the screen cannot decide, word by word (same scheme as k_step_fast below,
 // one lane doing all the words): sensed mask, occupancy/coverage bits, nearest cell (first minimum).
@@ -213,10 +242,10 @@ __device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, 
     const double px = pxf, py = pyf;
     unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;
     const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
-    const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
+    const f32x2 thr = {P.Tsen_f, P.Thalf_f};
     for (int w = 0; w < P.W; ++w) {
         unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
-        float amb = __builtin_inff();
+        float amb = __builtin_inff(), ambo = __builtin_inff();
         const float4 *X = reinterpret_cast<const float4 *>(gx + w * 32);
         const float4 *Y = reinterpret_cast<const float4 *>(gy + w * 32);
 #pragma unroll
@@ -234,25 +263,17 @@ __device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, 
                 k2 = umed3(k1, k2, key);
                 k1 = k1 < key ? k1 : key;
                 const f32x2 s2 = {sv, sv};
-                const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half_hi)
+                const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half)
                 word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
                 ocand = __builtin_amdgcn_alignbit(ocand, __float_as_uint(d.y), 31);
                 amb = __builtin_fminf(amb, __builtin_fabsf(d.x));
+                ambo = __builtin_fminf(ambo, __builtin_fabsf(d.y));
             }
         }
         mw[w] = __brev(word);
         wkey[w] = (unsigned short)(k1 >> 16);
         if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
-        ocand = active ? __brev(ocand) : 0u;
-        while (ocand) {                                                     // rare: exact occupancy / coverage test
-            const int b = __ffs(ocand) - 1; ocand &= ocand - 1;
-            const double rxd = (double)gx[w * 32 + b] - px, ryd = (double)gy[w * 32 + b] - py;
-            const double sd = rxd * rxd + ryd * ryd;
-            if (sd < P.T_half_le) {                                         // CPP:190  !(norm > r_avoid/2)
-                atomicOr(&occ[w], 1u << b);
-                if (sd < P.T_half_lt) atomicOr(&cov[w], 1u << b);           // WRAP:67
-            }
-        }
+        settle_occupancy(P, active, __brev(ocand), ambo, px, py, gx + w * 32, gy + w * 32, &occ[w], &cov[w]);
         if (k1 < G1) G1w = (unsigned)w;
         const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
         G2 = m < t ? m : t;
@@ -1149,12 +1170,12 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;   // ambw: words with an undecided sensed bit
         unsigned *wkey = reinterpret_cast<unsigned *>(L.sel);       // [64][MW], aliases the slot lists (written later)
         const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
-        const f32x2 thr = {P.Tsen_f, P.Thalf_hi_f};
+        const f32x2 thr = {P.Tsen_f, P.Thalf_f};
         // wave 0 also runs the k-NN pass above, so it takes only the first W0 words; the others share the rest
         const int W0 = T == 1 ? W : (W / T > ASM_W0_LESS ? W / T - ASM_W0_LESS : 0);
         for (int w = (T == 1 || sub == 0) ? 0 : W0 + sub - 1; w < ((T == 1 || sub != 0) ? W : W0); w += (T == 1 || sub == 0) ? 1 : T - 1) {
             unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
-            float amb = __builtin_inff();
+            float amb = __builtin_inff(), ambo = __builtin_inff();
             const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
             const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
 #pragma unroll
@@ -1173,26 +1194,17 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     k2 = umed3(k1, k2, key);
                     k1 = k1 < key ? k1 : key;
                     const f32x2 s2 = {s, s};
-                    const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half_hi)
+                    const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half)
                     word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
                     ocand = __builtin_amdgcn_alignbit(ocand, __float_as_uint(d.y), 31);
                     amb = __builtin_fminf(amb, __builtin_fabsf(d.x));
+                    ambo = __builtin_fminf(ambo, __builtin_fabsf(d.y));
                 }
             }
             L.mask[(size_t)l * MW + w] = __brev(word);
             wkey[(size_t)l * MW + w] = k1;                           // smallest key of the word, for the rare tie resolution
             if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
-            ocand = __brev(ocand);
-            if (!active) ocand = 0;
-            while (ocand) {                                         // rare: exact occupancy / coverage test
-                const int b = __ffs(ocand) - 1; ocand &= ocand - 1;
-                const double rxd = (double)gxe[w * 32 + b] - px, ryd = (double)gye[w * 32 + b] - py;
-                const double sd = rxd * rxd + ryd * ryd;
-                if (sd < P.T_half_le) {                             // CPP:190  !(norm > r_avoid/2)
-                    atomicOr(&occ_e[w], 1u << b);
-                    if (sd < P.T_half_lt) atomicOr(&cov_e[w], 1u << b);   // WRAP:67
-                }
-            }
+            settle_occupancy(P, active, __brev(ocand), ambo, px, py, gxe + w * 32, gye + w * 32, &occ_e[w], &cov_e[w]);
             if (k1 < G1) G1w = (unsigned)w;
             const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
             G2 = m < t ? m : t;
