@@ -983,52 +983,37 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int ng0 = e0 < P.E ? ng_g[e0] : 0, ng1 = e0 + 1 < P.E ? ng_g[e0 + 1] : 0;
     const int n_g = es ? ng1 : ng0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
-    // The grids are not needed before P3: with 4 waves, waves 2 and 3 fetch them during P1 while waves 0 and 1
-    // run the dynamics and the prior (unless the prior has to search the grid itself).
-    const bool late_grid = T >= 4 && !P.recompute;
-    constexpr int GQ = 8;                                           // float4 per loader thread, at most (n_g_max <= 1024)
-    float4 gv[GQ];
-    const int per_env4 = NGP / 2;                                   // float4 per environment (2 rows)
-    auto grid_issue = [&](int t, int nt, int off) {                 // thread t of nt loader threads, float4 off..: global loads only
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const int idx = off + q * nt + t;
-            gv[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
-            if (off + q * nt < NGP && idx < NGP) {                  // first test is wave-uniform: dead rounds issue nothing
-                const int h = idx >= per_env4, r = idx - h * per_env4;
-                if (e0 + h < P.E) gv[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)(e0 + h) * 2 * NGP + (size_t)r * 4);
-            }
-        }
-    };
-    auto grid_commit = [&](int t, int nt, int off) {                // cells beyond n_g -> far away, then into LDS
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const int idx = off + q * nt + t;
-            if (off + q * nt < NGP && idx < NGP) {
-                const int h = idx >= per_env4, r = idx - h * per_env4;
-                const int ngh = h ? ng1 : ng0;
-                const int c = r * 4 - (r * 4 >= NGP ? NGP : 0);
-                float4 u = gv[q];
-                if (c + 3 >= ngh) {                                 // only the last cells of a row lie beyond n_g
-                    if (c + 0 >= ngh) u.x = 1e30f;
-                    if (c + 1 >= ngh) u.y = 1e30f;
-                    if (c + 2 >= ngh) u.z = 1e30f;
-                    u.w = 1e30f;
-                }
-                *reinterpret_cast<float4 *>(L.g + (size_t)idx * 4) = u;
-            }
-        }
-    };
     {
         float sa = 1e30f, sb = 1e30f, sc = 0.f, sd = 0.f;
         if (sub == 0 && active) {
             const size_t o = (size_t)e * 2 * n_a;
             sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
         }
-        if (!late_grid) {                                           // GQ float4 per thread cover 1024 once T >= 2;
-            for (int off = 0; off < NGP; off += GQ * 64 * T) {      // a single wave goes twice
-                grid_issue(tid, 64 * T, off);
-                grid_commit(tid, 64 * T, off);
+        const int per_env4 = NGP / 2;                               // float4 per environment (2 rows)
+        for (int base = 0; base < NGP; base += 64 * T * 4) {
+            float4 v[4]; int idx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                idx[q] = base + q * 64 * T + tid;
+                v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                if (idx[q] < NGP) {
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
+                    if (e0 + h < P.E) v[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)(e0 + h) * 2 * NGP + (size_t)r * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (idx[q] < NGP) {
+                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
+                    const int ngh = h ? ng1 : ng0;
+                    const int c = r * 4 - (r * 4 >= NGP ? NGP : 0);
+                    float4 u = v[q];
+                    if (c + 0 >= ngh) u.x = 1e30f;
+                    if (c + 1 >= ngh) u.y = 1e30f;
+                    if (c + 2 >= ngh) u.z = 1e30f;
+                    if (c + 3 >= ngh) u.w = 1e30f;
+                    *reinterpret_cast<float4 *>(L.g + (size_t)idx[q] * 4) = u;
+                }
             }
         }
         for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
@@ -1103,15 +1088,12 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         } else {
             inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
         }
-        // CPP:896-901; while the grids are still on their way to LDS the target cell comes from memory
-        const float *gsrc = late_grid ? grid_g + (size_t)e * 2 * NGP : gxe;
-        const double tx = inf ? px : (double)gsrc[near], ty = inf ? py : (double)gsrc[NGP + near];
+        const double tx = inf ? px : (double)gxe[near], ty = inf ? py : (double)gye[near];      // CPP:896-901
         double f0, f1;
         prior_policy<float>(P, px, py, vx, vy, tx, ty, nb, L.px + es * 32, L.py + es * 32, L.vx + es * 32,
                             L.vy + es * 32, f0, f1);
         prior_g[(size_t)e * 2 * n_a + i] = (float)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (float)f1;
     }
-    if (late_grid && sub >= 2) { grid_issue(tid - 128, 64 * (T - 2), 0); grid_commit(tid - 128, 64 * (T - 2), 0); }
     STAMP(2);
     __syncthreads();                                                // all reads of the old state done
     if (sub == 0 && active) {
