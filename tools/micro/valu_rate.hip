@@ -11,8 +11,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int KIND>
 __global__ void k(unsigned *out, int iters, unsigned seed)
 {
-    unsigned a[8]; f32x2 p[8];
-    for (int q = 0; q < 8; ++q) { a[q] = seed * (threadIdx.x + 1) + q * 7919u; p[q] = f32x2{(float)(a[q] & 1023), (float)q}; }
+    unsigned a[8]; f32x2 p[8]; double d[8];
+    for (int q = 0; q < 8; ++q) { a[q] = seed * (threadIdx.x + 1) + q * 7919u; p[q] = f32x2{(float)(a[q] & 1023), (float)q}; d[q] = 1.0 + q * 1e-3 + (a[q] & 7); }
     const f32x2 c = {1.0001f, 0.5f};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -24,10 +24,15 @@ __global__ void k(unsigned *out, int iters, unsigned seed)
             if (KIND == 4) p[q] = p[q] - c;                                  // v_pk_add_f32
             if (KIND == 5) a[q] = (a[q] & ~31u) | (unsigned)q;               // v_and_or_b32
             if (KIND == 6) p[q].x = __builtin_fmaf(p[q].x, c.x, c.y);        // v_fma_f32
+            if (KIND == 7) d[q] = __builtin_fma(d[q], 1.0000001, 1e-9);      // v_fma_f64
+            if (KIND == 8) d[q] = d[q] + 1e-9;                               // v_add_f64
+            if (KIND == 9) d[q] = d[q] < d[(q + 1) & 7] ? d[q] : d[(q + 1) & 7] + 1.0;   // v_cmp_f64 + 2 v_cndmask + v_add_f64
+            if (KIND == 10) d[q] = 1.0 / d[q] + 1.5;                         // double division sequence
+            if (KIND == 11) d[q] = sqrt(d[q]) + 2.0;                         // double sqrt sequence
         }
     }
     unsigned r = 0;
-    for (int q = 0; q < 8; ++q) r ^= a[q] ^ __float_as_uint(p[q].x) ^ __float_as_uint(p[q].y);
+    for (int q = 0; q < 8; ++q) r ^= a[q] ^ __float_as_uint(p[q].x) ^ __float_as_uint(p[q].y) ^ (unsigned)__double_as_longlong(d[q]);
     if (r == 0x12345678u) out[0] = r;
 }
 
@@ -35,7 +40,7 @@ template <int KIND>
 static void run(const char *name)
 {
     unsigned *d; hipMalloc(&d, 4);
-    const int iters = 20000;
+    const int iters = KIND >= 10 ? 2000 : 20000;
     for (int wps = 1; wps <= 4; wps *= 2) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(256 * wps), 0, 0, d, 100, 3u);
@@ -54,6 +59,7 @@ static void run(const char *name)
 int main()
 {
     run<0>("v_alignbit"); run<1>("v_med3_u32"); run<2>("v_min_u32"); run<3>("v_pk_fma_f32"); run<4>("v_pk_add_f32");
-    run<5>("v_and_or_b32"); run<6>("v_fma_f32");
+    run<5>("v_and_or_b32"); run<6>("v_fma_f32"); run<7>("v_fma_f64"); run<8>("v_add_f64"); run<9>("f64 cmp+sel+add");
+    run<10>("f64 1/x + add"); run<11>("f64 sqrt + add");
     return 0;
 }
