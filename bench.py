@@ -37,14 +37,14 @@ def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
     return 872.0 + 8.0 * n_g_mean / n_a
 
 
-def measured_traffic(E: int, n_a: int):
+def measured_traffic(E: int, n_a: int, S: int):
     """HBM bytes per k_step launch and VALU busy from the committed rocprofv3 PMC passes (profiles/r01_pmc.json),
     if they were taken on this workload; None otherwise (counters cannot be read from inside this process)."""
     path = os.path.join(REPO, "profiles", "r01_pmc.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if t["workload"] == {"envs_per_gpu": E, "agents": n_a}:
+        if t["workload"] == {"envs_per_gpu": E, "agents": n_a, "streams": S}:
             return t
     except (OSError, ValueError, KeyError):
         pass
@@ -95,10 +95,12 @@ def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--agents", type=int, default=30)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-indices", action="store_true", help="also materialise sensed/occupied index lists")
     ap.add_argument("--regime", choices=["random", "packed"], default="random",
@@ -108,8 +110,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from marl_amd.batched import BatchedAssemblyEnv
-    from marl_amd.sharding import shard_range, reduce_episode_stats
+    from marl_amd.sharding import StreamShards, shard_range, reduce_episode_stats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,24 +140,32 @@ def main():
             print(f"[bench rank {rank}] {what}", file=sys.stderr, flush=True)
 
     mark("process group ready")
-    E, n_a, K, W = args.envs_per_gpu, args.agents, args.steps, args.warmup
-    env = BatchedAssemblyEnv(E, n_a, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0], keep_indices=args.keep_indices)
+    E, n_a, K, W, S = args.envs_per_gpu, args.agents, args.steps, args.warmup, args.streams
+    # The rank's environments as S shards on S HIP streams (contiguous global ids: the same environments
+    # as one batch of E); S launches are in flight, one shard's ramp and tail under the other's steady state.
+    shards = StreamShards(E, n_a, parts=S, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0],
+                          keep_indices=args.keep_indices)
 
-    def reset_env(episode=None):
+    def reset_one(k, env, episode=None):
         env.reset(episode=episode)
         if args.regime == "packed":                           # agents onto random cells of their own shape, + 2 cm jitter
-            g = torch.Generator(device=device).manual_seed(1000 + env.episode)
-            cell = (torch.rand(E, n_a, device=device, generator=g) * env.n_g[:, None]).long().clamp_(max=env.n_g_max - 1)
-            pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a))
-            env.p.copy_(pos + 0.02 * torch.randn(E, 2, n_a, device=device, generator=g))
+            g = torch.Generator(device=device).manual_seed(1000 + 7 * env.episode + k)
+            cell = (torch.rand(env.E, n_a, device=device, generator=g) * env.n_g[:, None]).long().clamp_(max=env.n_g_max - 1)
+            pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(env.E, 2, n_a))
+            env.p.copy_(pos + 0.02 * torch.randn(env.E, 2, n_a, device=device, generator=g))
             env.observe()
 
-    reset_env(episode=0)
+    shards.on_each(lambda k, env: reset_one(k, env, 0))
     ring = min(max(K, 1), 64)
-    actions = torch.empty(ring, E, 2, n_a, dtype=torch.float32, device=device)
-    for k in range(ring):
-        env.random_actions(out=actions[k], step=k)
-    n_g_mean = float(env.n_g.double().mean())
+
+    def draw_actions(k, env):
+        a = torch.empty(ring, env.E, 2, n_a, dtype=torch.float32, device=device)
+        for j in range(ring):
+            env.random_actions(out=a[j], step=j)
+        return a
+
+    actions = shards.on_each(draw_actions)
+    n_g_mean = float(torch.cat(shards.on_each(lambda k, env: env.n_g.double())).mean())
     totals = torch.zeros(8, dtype=torch.float64, device=device)
 
     def barrier():
@@ -166,29 +175,33 @@ def main():
 
     def run_steps(n, t0=0):
         for t in range(t0, t0 + n):
-            env.step(actions[t % ring])
+            shards.step([a[t % ring] for a in actions])
             if (t + 1) % EPISODE_LENGTH == 0:               # end of episode (TRAIN:99,107,177-197)
-                totals.add_(reduce_episode_stats(env.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
-                reset_env()
+                totals.add_(reduce_episode_stats(shards.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
+                shards.on_each(reset_one)
 
     # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
+    barrier()
     mark("environment reset, actions drawn")
     run_steps(W)
     mark("warm-up steps done")
-    totals.add_(reduce_episode_stats(env.episode_stats())).zero_()
+    totals.add_(reduce_episode_stats(shards.episode_stats())).zero_()
     mark("warm-up all-reduce done")
     barrier()
     mark("barrier passed, timing")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
     t0 = time.perf_counter()
-    ev0.record()
+    for k in range(S):
+        evs[k][0].record(shards.streams[k])
     run_steps(K, W)
-    ev1.record()
+    for k in range(S):
+        evs[k][1].record(shards.streams[k])
     barrier()
     mark("timed region done")
     wall = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    # per stream: K launches back to back -> the average launch duration of the step kernel on that stream
+    ev_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -199,9 +212,11 @@ def main():
         value = agent_steps / wall
         b_alg = b_alg_per_agent_step(n_a, n_g_mean)
         resets = sum(1 for t in range(W, W + K) if (t + 1) % EPISODE_LENGTH == 0)
-        kern_ms = ev_ms / K                                   # k_step launches back to back on one stream
-        achieved = E * n_a * b_alg / (kern_ms * 1e-3) / 1e9
-        tr = measured_traffic(E, n_a)
+        kern_ms = ev_ms / K                                   # step launches run back to back on each stream
+        per_launch = E / S * n_a                              # agent-steps of one launch (one shard)
+        # S launches are in flight at any time, so the device moves S launches' bytes per launch duration
+        achieved = S * per_launch * b_alg / (kern_ms * 1e-3) / 1e9
+        tr = measured_traffic(E, n_a, S)
         out = {
             "metric": "agent-steps/sec (whole node) for batched 30-agent assembly envs at 1/2/4/8 GPUs",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -213,22 +228,24 @@ def main():
                        "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
                        "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,
                        "state": "float32 in HBM; decisions evaluated in float64",
-                       "parallelism": f"env-sharded x{world}, RCCL all-reduce of 8 doubles per episode"},
+                       "streams_per_gpu": S,
+                       "parallelism": f"env-sharded x{world} GPUs x{S} HIP streams, RCCL all-reduce of 8 doubles per episode"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # PMC bytes per launch / this run's launch time, same unit as `achieved`
-                         "traffic": (tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
+                         # PMC bytes per launch x launches in flight / this run's launch time, same unit as `achieved`
+                         "traffic": (S * tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
                          "traffic_bytes_per_launch": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": "profiles/r01_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
-                         # rocprof's VALUBusy formula on the same PMC passes: the kernel is bound by instruction
-                         # issue, not by bandwidth
-                         "valu_busy": tr.get("valu_busy") if tr else None,
-                         "alg_bytes_per_launch": E * n_a * b_alg,
+                         # rocprof's VALUBusy formula on the same PMC passes (counters serialise the launches, so
+                         # this is one launch alone on the chip): the kernel is bound by instruction issue
+                         "valu_busy_one_launch": tr.get("valu_busy") if tr else None,
+                         "launches_in_flight": S, "achieved_per_launch": achieved / S,
+                         "alg_bytes_per_launch": per_launch * b_alg,
                          "kernel": "k_step_fast / k_step (asm_batch_step_f32)", "avg_launch_ms": kern_ms,
-                         "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": E * n_a},
+                         "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n_a, env.r_avoid)
+            out["cpu_baseline"] = cpu_baseline(n_a, shards.envs[0].r_avoid)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -92,6 +92,8 @@ class BatchedAssemblyEnv:
         self._shape_ng = torch.tensor(self.n_gs, **i32)
         self._shape_lcell = torch.tensor(self.l_cells, dtype=torch.float64, device=dev)
         self._recompute_target = False
+        self._step_sig, self._step_args = None, None
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     # ------------------------------------------------------------------
     def _stream(self):
@@ -139,12 +141,23 @@ class BatchedAssemblyEnv:
                 tuple(a.shape) != (self.E, 2, self.n_a):
             raise ValueError(f"actions must be a contiguous float32 tensor of shape {(self.E, 2, self.n_a)} on {self.device}")
         prior = self.a_prior if self.training_method == "llm_rl" else None
-        with torch.cuda.device(self.device):
-            rc = self.lib.asm_batch_step_f32(
-                C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), _ptr(a), _ptr(self.grid_center),
-                _ptr(self.n_g), _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags),
-                _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior), _ptr(self.sensed_index),
-                _ptr(self.occupied_index), _ptr(self.stats), int(self._recompute_target), self._stream())
+        # the argument list only changes when an output tensor is re-pointed (DeviceReplay does that); building
+        # 17 ctypes pointers per call would otherwise cost more host time than a short launch takes on the GPU
+        sig = (self.obs.data_ptr(), self.reward.data_ptr(), 0 if prior is None else prior.data_ptr(), self.p.data_ptr(),
+               self.dp.data_ptr())
+        if self._step_sig != sig:
+            self._step_sig = sig
+            self._step_args = [C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), None, _ptr(self.grid_center),
+                               _ptr(self.n_g), _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags),
+                               _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior),
+                               _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.stats), 0, None]
+        args = self._step_args
+        args[4] = C.c_void_p(a.data_ptr()); args[17] = int(self._recompute_target); args[18] = self._stream()
+        if torch.cuda.current_device() == self._dev_index:
+            rc = self.lib.asm_batch_step_f32(*args)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self.lib.asm_batch_step_f32(*args)
         _lib.check(rc, "asm_batch_step_f32")
         self._recompute_target = False
         self.step_count += 1

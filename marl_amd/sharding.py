@@ -45,3 +45,57 @@ def summarize(stats: torch.Tensor, n_a: int) -> dict:
     return {"reward_mean": mean_r, "reward_std": max(s[1] / (steps * n_a) - mean_r ** 2, 0.0) ** 0.5,
             "coverage": s[2] / steps, "uniformity": s[3] / steps, "collisions_per_step": s[4] / steps,
             "avg_distance_to_target": s[5] / steps, "inside_fraction": s[7] / (steps * n_a)}
+
+
+class StreamShards:
+    """One GPU's environments as `parts` independent BatchedAssemblyEnv shards, each on its own HIP stream.
+
+    A single launch over all environments leaves the chip part-empty while its workgroups ramp up and
+    while the last ones drain; with two launches in flight, one shard's ramp and tail run under the other
+    shard's steady state (4096 environments on one MI355X: 72 -> 55 us per step of the whole batch).
+    The shards own contiguous global environment ids, so together they are exactly the environments of
+    one BatchedAssemblyEnv(num_envs, env_id_offset=...).  Each shard is driven on its stream; nothing
+    orders the shards against each other until synchronize() or episode_stats().
+    """
+
+    def __init__(self, num_envs: int, n_a: int = 30, *, parts: int = 2, device="cuda", env_id_offset: int = 0, **env_kw):
+        from .batched import BatchedAssemblyEnv
+        if parts < 1 or num_envs < parts:
+            raise ValueError("need at least one environment per shard")
+        self.device = torch.device(device)
+        self.parts, self.E, self.n_a = parts, int(num_envs), int(n_a)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self.envs = []
+        first = 0
+        for k in range(parts):
+            _, count = split_range(self.E, k, parts)
+            with torch.cuda.stream(self.streams[k]):
+                self.envs.append(BatchedAssemblyEnv(count, n_a, device=self.device, env_id_offset=env_id_offset + first, **env_kw))
+            first += count
+
+    def on_each(self, fn):
+        """fn(k, env) for every shard with the shard's stream current; returns the list of results."""
+        out = []
+        for k, env in enumerate(self.envs):
+            with torch.cuda.stream(self.streams[k]):
+                out.append(fn(k, env))
+        return out
+
+    def reset(self, episode=None):
+        return self.on_each(lambda k, env: env.reset(episode))
+
+    def step(self, actions):
+        """actions: one (E_k, 2, n_a) tensor per shard, produced on that shard's stream."""
+        return self.on_each(lambda k, env: env.step(actions[k]))
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
+
+    def episode_stats(self) -> torch.Tensor:
+        """Sum of the shards' 8-value vectors, on the current stream (which waits for the shards)."""
+        cur = torch.cuda.current_stream(self.device)
+        parts = self.on_each(lambda k, env: env.episode_stats())
+        for s in self.streams:
+            cur.wait_stream(s)
+        return torch.stack(parts).sum(dim=0)

@@ -16,6 +16,7 @@ ap.add_argument("pattern", nargs="?", default="k_step")
 ap.add_argument("--json")
 ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--agents", type=int, default=30)
+ap.add_argument("--streams", type=int, default=2)
 a = ap.parse_args()
 
 acc = collections.defaultdict(list)
@@ -30,7 +31,7 @@ for k, v in acc.items():
     print(f"{k:32s} launches={len(v):4d} mean={mean[k]:16.1f}")
 
 if a.json:
-    rec = {"workload": {"envs_per_gpu": a.envs, "agents": a.agents}, "kernel": sorted(names),
+    rec = {"workload": {"envs_per_gpu": a.envs, "agents": a.agents, "streams": a.streams}, "kernel": sorted(names),
            "source": "rocprofv3 --pmc, one pass per counter group (tools/pmc.sh), bench.py --steps 50; mean over the launches",
            "counters": {k: round(v, 1) for k, v in sorted(mean.items())}}
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
