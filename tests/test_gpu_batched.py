@@ -324,3 +324,29 @@ def test_argument_errors(torch_cuda):
     import torch
     with pytest.raises(ValueError):
         env.step(torch.zeros(2, 2, 29, device="cuda"))
+
+
+def test_stream_shards_are_the_same_environments(torch_cuda):
+    """Two shards on two HIP streams (marl_amd.sharding.StreamShards) against one batch of the same global ids."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.sharding import StreamShards
+    E, n_a = 37, 30
+    one = BatchedAssemblyEnv(E, n_a, seed=9, env_id_offset=100)
+    two = StreamShards(E, n_a, parts=2, seed=9, env_id_offset=100)
+    assert [e.E for e in two.envs] == [19, 18] and [e.env_id_offset for e in two.envs] == [100, 119]
+    o1 = one.reset()
+    o2 = two.reset()
+    two.synchronize()
+    assert torch.equal(o1, torch.cat(o2))
+    for t in range(7):
+        a = one.random_actions(step=t)
+        parts = two.on_each(lambda k, env: env.random_actions(step=t))
+        two.synchronize()
+        assert torch.equal(a, torch.cat(parts))
+        r1 = one.step(a)
+        r2 = two.step(parts)
+        two.synchronize()
+        for j in (0, 1, 4):
+            assert torch.equal(r1[j], torch.cat([r[j] for r in r2]))
+    assert torch.allclose(one.episode_stats(), two.episode_stats(), rtol=1e-12, atol=0)
