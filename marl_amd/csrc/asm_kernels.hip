@@ -968,7 +968,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                                                       double *stats_g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, sub = tid >> 6, l = tid & 63, es = l >> 5, i = l & 31;
+    // sub is the same for every lane of a wave: read through the scalar unit so that everything derived from
+    // it (word and slot ranges, row offsets) stays in scalar registers
+    const int tid = threadIdx.x, sub = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, es = l >> 5, i = l & 31;
     const int e = blockIdx.x * 2 + es;
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
