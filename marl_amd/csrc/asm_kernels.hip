@@ -1109,7 +1109,15 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // ---- P3: agent x cell pass on the NEW state, words split over the waves ------------
     const float pxf = L.px[l], pyf = L.py[l];
     const double px = pxf, py = pyf;
-    float *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;          // obs[row * n_a + agent]
+    // obs[row * n_a + agent] of this lane's environment, written with buffer stores: resource = the block of the
+    // workgroup's two environments, vector offset = the lane's column, scalar offset = the row; a row store then
+    // needs no vector address arithmetic
+    const __amdgpu_buffer_rsrc_t obs_rs =
+        __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e0 * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
+    const int olb = (es * P.obs_dim * n_a + i) * 4;
+    auto ostore = [&](int row, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, 0);
+    };
     double s6[6]; int j6[6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
@@ -1152,7 +1160,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         // correctly rounded difference, identical to rounding the double difference
         const float vxf = L.vx[l], vyf = L.vy[l];
         int r0 = 0;
-        if (P.con_self) { ocol[0] = pxf; ocol[(size_t)n_a] = pyf; ocol[(size_t)2 * n_a] = vxf; ocol[(size_t)3 * n_a] = vyf; r0 = 4; }
+        if (P.con_self) { ostore(0, pxf); ostore(1, pyf); ostore(2, vxf); ostore(3, vyf); r0 = 4; }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const int j = j6[q];
@@ -1162,8 +1170,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 wx = L.vx[es * 32 + j] - vxf; wy = L.vy[es * 32 + j] - vyf;      // CPP:86
             }
             nbr_g[((size_t)e * n_a + i) * 6 + q] = j;               // CPP:103-105
-            const size_t r = (size_t)(r0 + 4 * q) * n_a;
-            ocol[r] = rx; ocol[r + n_a] = ry; ocol[r + 2 * (size_t)n_a] = wx; ocol[r + 3 * (size_t)n_a] = wy;
+            const int r = r0 + 4 * q;
+            ostore(r, rx); ostore(r + 1, ry); ostore(r + 2, wx); ostore(r + 3, wy);
         }
     }
     STAMP(4);
@@ -1277,8 +1285,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
             if (!in_flag) { t0 = gxe[imin] - pxf; t1 = gye[imin] - pyf; t2 = 0.f - L.vx[l]; t3 = 0.f - L.vy[l]; }
             const int tb = P.obs_dim - (2 + cap) * 2;               // CPP:304
-            ocol[(size_t)(tb + 0) * n_a] = t0; ocol[(size_t)(tb + 1) * n_a] = t1;
-            ocol[(size_t)(tb + 2) * n_a] = t2; ocol[(size_t)(tb + 3) * n_a] = t3;
+            ostore(tb + 0, t0); ostore(tb + 1, t1);
+            ostore(tb + 2, t2); ostore(tb + 3, t3);
         } else {
             L.fin[l] = 0;
         }
@@ -1412,7 +1420,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             for (int kb = k0; kb < k1; kb += RB) {
                 int cell[RB]; float cx[RB], cy[RB]; bool have[RB];
 #pragma unroll
-                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? (int)mysel[kb + q] : 0; }
+                for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q < k1 ? kb + q : k1 - 1];   // unconditional: one batch of LDS reads
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? cell[q] : 0; }
 #pragma unroll
                 for (int q = 0; q < RB; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
 #pragma unroll
@@ -1421,7 +1431,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     if (k < k1) {
                         const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
 #ifndef ASM_EXP_NOSTORE
-                        ocol[(size_t)(gb + 2 * k) * n_a] = gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = gy;
+                        ostore(gb + 2 * k, gx); ostore(gb + 2 * k + 1, gy);
 #endif
                         if (sdst) sdst[k] = have[q] ? cell[q] : -1;
                         // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
