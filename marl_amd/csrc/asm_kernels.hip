@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int n_g = es ? ng1 : ng0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     {
-        float sa = 1e30f, sb = 1e30f, sc = 0.f, sd = 0.f;
+        float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
         if (sub == 0 && active) {
             const size_t o = (size_t)e * 2 * n_a;
             sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
@@ -1301,17 +1301,22 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const unsigned *mym = L.mask + (size_t)l * MW;
     const unsigned inm = in_flag ? 0xFFFFFFFFu : 0u;                // CPP:155: occupied cells drop out only inside the shape
     const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
-    int n_after = 0, wst = 0, bst = 0;
+    // Unused lanes sit at -1e30 (P0), so their masks are empty.  The words whose first rank lies below k0 form a
+    // prefix of nb words; this wave starts at the first non-empty word after them, whose first rank is bst.
+    int n_after = 0, nb = 0, bst = 0;
     unsigned nz = 0;                                                // words with a cell that stays in the list
-    bool found = false;
     for (int w = 0; w < W; ++w) {
-        unsigned f = mym[w] & ~(occ_e[w] & inm);
-        if (!active) f = 0;
+        const unsigned f = mym[w] & ~(occ_e[w] & inm);
         const int pc = __popc(f);
-        if (pc && !found && n_after >= k0) { wst = w; bst = n_after; found = true; }   // first word whose ranks start at or after k0
-        if (pc) nz |= 1u << w;
+        const bool below = n_after < k0;
         n_after += pc;
+        nb += below ? 1 : 0;
+        bst = below ? n_after : bst;
+        nz |= (unsigned)(pc < 1 ? pc : 1) << w;
     }
+    const unsigned nzs = nb >= 32 ? 0u : nz & (0xFFFFFFFFu << nb);
+    const bool found = nzs != 0;
+    const int wst = found ? __ffs(nzs) - 1 : 0;
     const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
     STAMP(16);
