@@ -991,30 +991,34 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const size_t o = (size_t)e * 2 * n_a;
             sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
         }
-        const int per_env4 = NGP / 2;                               // float4 per environment (2 rows)
-        for (int base = 0; base < NGP; base += 64 * T * 4) {
-            float4 v[4]; int idx[4];
+        // The four coordinate rows (2 environments x {x, y}) are dealt out to the waves, so the row and its n_g are
+        // wave-uniform and a lane's float4 index is just l, l + 64, ...; cells beyond n_g become far-away padding.
+        for (int row = sub; row < 4; row += T) {
+            const int h = row >> 1, ngh = h ? ng1 : ng0;
+            const bool row_ok = e0 + h < P.E;
+            const float *src = grid_g + ((size_t)(e0 + h) * 2 + (row & 1)) * NGP;
+            float *dst = L.g + (size_t)row * NGP;
+            for (int base = 0; base < NGP; base += 64 * 4 * 4) {
+                float4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                idx[q] = base + q * 64 * T + tid;
-                v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
-                if (idx[q] < NGP) {
-                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
-                    if (e0 + h < P.E) v[q] = *reinterpret_cast<const float4 *>(grid_g + (size_t)(e0 + h) * 2 * NGP + (size_t)r * 4);
+                for (int q = 0; q < 4; ++q) {
+                    const int c = base + (q * 64 + l) * 4;
+                    v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                    if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (idx[q] < NGP) {
-                    const int h = idx[q] >= per_env4, r = idx[q] - h * per_env4;
-                    const int ngh = h ? ng1 : ng0;
-                    const int c = r * 4 - (r * 4 >= NGP ? NGP : 0);
-                    float4 u = v[q];
-                    if (c + 0 >= ngh) u.x = 1e30f;
-                    if (c + 1 >= ngh) u.y = 1e30f;
-                    if (c + 2 >= ngh) u.z = 1e30f;
-                    if (c + 3 >= ngh) u.w = 1e30f;
-                    *reinterpret_cast<float4 *>(L.g + (size_t)idx[q] * 4) = u;
+                for (int q = 0; q < 4; ++q) {
+                    const int c = base + (q * 64 + l) * 4;
+                    if (base + q * 256 < NGP && c < NGP) {
+                        float4 u = v[q];
+                        if (c + 3 >= ngh) {                         // only the last cells of a row lie beyond n_g
+                            if (c + 0 >= ngh) u.x = 1e30f;
+                            if (c + 1 >= ngh) u.y = 1e30f;
+                            if (c + 2 >= ngh) u.z = 1e30f;
+                            u.w = 1e30f;
+                        }
+                        *reinterpret_cast<float4 *>(dst + c) = u;
+                    }
                 }
             }
         }
