@@ -181,6 +181,19 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
 int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a,
                                  float *act, void *stream);
 
+/*
+ * Formation metrics of the wrapper (assembly_wrapper.py:48-165, get_formation_metrics :167-187) for the
+ * current positions of every environment, evaluated in double with the reference's definitions:
+ *   metrics [E][5] double = { coverage_rate (:48-72), distribution_uniformity (:74-101),
+ *                             voronoi_based_uniformity (:103-129), contact pairs of the given positions
+ *                             (upper triangle of ENV:445-446, what :131-145 counts), average_distance_to_target
+ *                             (:147-165) }
+ * eval_assembly.py:156-158 evaluates them once per step of an evaluation episode.  The two uniformity
+ * values are 0/0 = NaN when all agents are equidistant / own equally many cells, as in the reference.
+ */
+int asm_batch_metrics_f64(const asm_params *prm, int E, const float *p, const float *grid, const int32_t *n_g,
+                          double *metrics, void *stream);
+
 /* ---- Group C: on-device replay of batched rollouts ------------------------------------------
  * Counterpart of ReplayBufferAgent (marl_llm/algorithm/utils/buffer_agent.py:21-177) for the batched
  * environment.  Storage is caller-owned device memory, organised by episode slots of `episode_length`

@@ -173,6 +173,42 @@ class BatchedAssemblyEnv:
         _lib.check(rc, "asm_batch_random_actions_f32")
         return out
 
+    METRIC_FIELDS = ("coverage_rate", "distribution_uniformity", "voronoi_uniformity", "num_collisions",
+                     "avg_distance_to_target")
+
+    def formation_metrics(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(E, 5) float64: the wrapper's get_formation_metrics (assembly_wrapper.py:167-187) of the current
+        positions of every environment, columns as METRIC_FIELDS.  num_collisions counts the contact pairs of
+        the current positions (the reference's count reads the matrix its last step stored, i.e. the positions
+        that step started from: call this before step() to get that number)."""
+        if out is None:
+            out = torch.empty(self.E, 5, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_metrics_f64(C.byref(self.params), self.E, _ptr(self.p), _ptr(self.grid_center),
+                                                _ptr(self.n_g), _ptr(out), self._stream())
+        _lib.check(rc, "asm_batch_metrics_f64")
+        return out
+
+    def set_shape(self, shape_index: int, env_ids: Optional[torch.Tensor] = None) -> None:
+        """Switch environments (all, or the given ids) to canonical shape `shape_index`, unrotated and centred,
+        keeping the agents where they are: eval_assembly.py:17-57 (process_shape).  The next step's prior then
+        searches its target cell on the new grid (AssemblyEnv.cpp:1107), as the reference's does every step."""
+        k = int(shape_index)
+        if not 0 <= k < self.num_train_shape:
+            raise IndexError(f"shape {k}: {self.num_train_shape} shapes are loaded")
+        n_g = self.n_gs[k]
+        if n_g > self.n_g_max:
+            raise ValueError(f"shape {k} has {n_g} cells, the grid arrays hold {self.n_g_max}")
+        o = int(self._shape_off[k])
+        row = torch.zeros(2, self.n_g_max, dtype=torch.float32, device=self.device)   # cells beyond n_g are never read
+        row[:, :n_g] = self._shape_grids[o:o + n_g].T.to(torch.float32)
+        sel = slice(None) if env_ids is None else env_ids.to(self.device, torch.long)
+        self.grid_center[sel] = row
+        self.n_g[sel] = n_g
+        self.l_cell[sel] = self.l_cells[k]
+        self.shape_id[sel] = k
+        self._recompute_target = True
+
     def episode_stats(self) -> torch.Tensor:
         """[sum r, sum r^2, sum coverage, sum uniformity, sum contacts, sum avg-distance, steps, sum inside]
         summed over this rank's environments (float64, 8 values) — the vector that is

@@ -268,6 +268,18 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
     return rc ? hip_fail(rc, "asm_batch_random_actions_f32") : 0;
 }
 
+int asm_batch_metrics_f64(const asm_params *prm, int E, const float *p, const float *grid, const int32_t *n_g,
+                          double *metrics, void *stream)
+{
+    if (!prm || E < 1 || !p || !grid || !n_g || !metrics) return fail(1, "asm_batch_metrics_f64: bad arguments");
+    if (prm->n_a < 1 || prm->n_a > asmenv::ASM_MAX_AGENTS)
+        return fail(1, "n_a = %d: supported range is 1..%d", prm->n_a, asmenv::ASM_MAX_AGENTS);
+    if (prm->n_g_max < 1) return fail(1, "asm_batch_metrics_f64: n_g_max = %d", prm->n_g_max);
+    int rc = asmenv::launch_metrics(E, prm->n_a, prm->n_g_max, prm->r_avoid, prm->size_a, p, grid, n_g, metrics,
+                                    (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_metrics_f64") : 0;
+}
+
 int asm_replay_draw_indices(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *index, void *stream)
 {
     if (N < 1 || hi <= lo || !index) return fail(1, "asm_replay_draw_indices: bad arguments");

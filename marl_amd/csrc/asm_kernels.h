@@ -6,6 +6,8 @@
 
 namespace asmenv {
 
+constexpr int ASM_MAX_AGENTS = 1024;   // largest n_a the entry points accept
+
 // Kernel parameters, passed by value.  The T_* members are squared-distance
 // thresholds: for a threshold t of the reference, T = min{ s : fl(sqrt(s)) >= t } so that
 // fl(sqrt(s)) < t  <=>  s < T exactly (T_*_le: min{ s : fl(sqrt(s)) > t }, so that
@@ -51,6 +53,8 @@ int launch_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, 
 int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ring, const float *act_ring,
                          const float *prior_ring, const float *rew_ring, const int64_t *index, int N, float *obs_out,
                          float *act_out, float *rew_out, float *next_out, float *prior_out, hipStream_t st);
+int launch_metrics(int E, int n_a, int NGP, double r_avoid, double size_a, const float *p, const float *grid,
+                   const int *n_g, double *out, hipStream_t st);
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st);
 int launch_cos_f32_err(uint32_t lo, uint32_t hi, double *out_max, hipStream_t st);
 int launch_reward_compat(const DevParams &P, const double *p, const double *grid, int n_g, const int *nbr,

@@ -1680,6 +1680,84 @@ __global__ void k_replay_gather(int E, int n_a, int obs_dim, int T, const float 
     if (lane == 2) rew_out[k] = rew_ring[(size_t)q * n_a + i];
 }
 
+// Formation metrics of WRAP:48-165 for the given positions, one workgroup per environment, all in double with
+// the reference's definitions (distances are norms, i.e. square roots; argmin/min keep the first minimum; sums
+// run left to right).  out[e] = {coverage_rate, distribution_uniformity, voronoi_uniformity, contact pairs,
+// average_distance_to_target} (the order of WRAP:181-186).
+__global__ void __launch_bounds__(256) k_metrics(int n_a, int NGP, double r_half, double sizes2, const float *p_g,
+                                                 const float *grid_g, const int *ng_g, double *out)
+{
+    __shared__ double px[ASM_MAX_AGENTS], py[ASM_MAX_AGENTS], md[ASM_MAX_AGENTS], mg[ASM_MAX_AGENTS];
+    __shared__ int cnt[ASM_MAX_AGENTS];
+    __shared__ int covered, contacts;
+    const int e = blockIdx.x, tid = threadIdx.x, n_g = ng_g[e];
+    const float *gx = grid_g + (size_t)e * 2 * NGP, *gy = gx + NGP;
+    for (int j = tid; j < n_a; j += 256) {
+        px[j] = (double)p_g[(size_t)e * 2 * n_a + j]; py[j] = (double)p_g[(size_t)e * 2 * n_a + n_a + j];
+        cnt[j] = 0;
+    }
+    if (tid == 0) { covered = 0; contacts = 0; }
+    __syncthreads();
+    for (int g = tid; g < n_g; g += 256) {                          // WRAP:48-72 and 103-129: per cell
+        const double cx = (double)gx[g], cy = (double)gy[g];
+        double dmin = __builtin_inf(); int jmin = 0; bool any = false;
+        for (int j = 0; j < n_a; ++j) {
+            const double dx = px[j] - cx, dy = py[j] - cy;
+            const double d = sqrt(dx * dx + dy * dy);
+            if (d < dmin) { dmin = d; jmin = j; }                   // np.argmin: first minimum
+            any |= d < r_half;                                      // WRAP:67
+        }
+        atomicAdd(&cnt[jmin], 1);
+        if (any) atomicAdd(&covered, 1);
+    }
+    for (int i = tid; i < n_a; i += 256) {                          // WRAP:74-101, 131-145, 147-165: per agent
+        double m = __builtin_inf(); int c = 0;
+        for (int j = 0; j < n_a; ++j) {
+            const double dx = px[j] - px[i], dy = py[j] - py[i];
+            const double d = sqrt(dx * dx + dy * dy);
+            if (d != 0 && d < m) m = d;                             // WRAP:93-94
+            if (j > i && d - sizes2 < 0) ++c;                       // ENV:445-446, upper triangle WRAP:142
+        }
+        md[i] = m;
+        double t = __builtin_inf();
+        for (int g = 0; g < n_g; ++g) {
+            const double dx = (double)gx[g] - px[i], dy = (double)gy[g] - py[i];
+            const double d = sqrt(dx * dx + dy * dy);
+            if (d < t) t = d;
+        }
+        mg[i] = t;
+        if (c) atomicAdd(&contacts, c);
+    }
+    __syncthreads();
+    if (tid < 3) {                                                  // three independent left-to-right reductions
+        double r;
+        if (tid == 2) {
+            double tot = 0.0;
+            for (int i = 0; i < n_a; ++i) tot += mg[i];
+            r = tot / n_a;                                          // WRAP:163
+        } else {
+            double mean = 0.0, lo = __builtin_inf(), hi = -__builtin_inf();
+            for (int i = 0; i < n_a; ++i) {
+                const double x = tid == 0 ? md[i] : (double)cnt[i];
+                mean += x; lo = fmin(lo, x); hi = fmax(hi, x);
+            }
+            mean /= n_a;
+            double var = 0.0;
+            for (int i = 0; i < n_a; ++i) {
+                const double x = tid == 0 ? md[i] : (double)cnt[i];
+                var += (x - mean) * (x - mean);
+            }
+            var /= n_a;
+            r = (var - lo) / (hi - lo);                             // WRAP:99, 127
+        }
+        out[(size_t)e * 5 + (tid == 0 ? 1 : tid == 1 ? 2 : 4)] = r;
+    }
+    if (tid == 3) {
+        out[(size_t)e * 5 + 0] = (double)covered / n_g;             // WRAP:70
+        out[(size_t)e * 5 + 3] = (double)contacts;
+    }
+}
+
 __global__ void k_sqrt_f64(const double *in, double *out, int n)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1932,6 +2010,14 @@ int launch_cos_f32_err(uint32_t lo, uint32_t hi, double *out_max, hipStream_t st
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 64);
     hipLaunchKernelGGL(k_cos_f32_err, dim3(blocks), dim3(256), 0, st, lo, hi, reinterpret_cast<unsigned long long *>(out_max));
     return (int)hipGetLastError();
+}
+
+int launch_metrics(int E, int n_a, int NGP, double r_avoid, double size_a, const float *p, const float *grid,
+                   const int *n_g, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)E), dim3(256), 0, st, n_a, NGP, r_avoid / 2, 2 * size_a, p, grid, n_g, out);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st)

@@ -118,6 +118,28 @@ def run_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
     return reduce_episode_stats(env.episode_stats())
 
 
+@torch.no_grad()
+def eval_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, episode_length: int = 300,
+                 shape_schedule: Optional[dict] = None):
+    """eval_assembly.py:115-190 for E environments: one reset, then `episode_length` noise-free steps; before
+    step t the environments switch to shape `shape_schedule[t]` when t is a key (eval_assembly.py:149-153,
+    process_shape), and the formation metrics of the current state are recorded (:155-170).
+    Returns (metrics (episode_length, E, 5) float64 on the device, columns BatchedAssemblyEnv.METRIC_FIELDS,
+    total reward per environment (E,))."""
+    obs = env.reset()
+    metrics = torch.empty(episode_length, env.E, 5, dtype=torch.float64, device=env.device)
+    total = torch.zeros(env.E, dtype=torch.float64, device=env.device)
+    a = torch.empty(env.E, 2, env.n_a, dtype=torch.float32, device=env.device)
+    for t in range(episode_length):
+        if shape_schedule and t in shape_schedule:
+            env.set_shape(shape_schedule[t])
+        env.formation_metrics(metrics[t])
+        learner.act(obs, a)                                                # explore=False: no noise (:123, :174)
+        obs, rew = env.step(a)[:2]
+        total += rew.sum(dim=(1, 2), dtype=torch.float64)
+    return metrics, total
+
+
 def train_phase(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceReplay, batch_size: int = 2048,
                 num_updates: Optional[int] = None):
     """train_assembly.py:141-157."""
