@@ -184,6 +184,14 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
+// v_min3_u32
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Bit b of the result: fl32 |(X[b], Y[b]) - (px, py)|^2 < thr, b = 0..31 (X, Y 16-byte aligned in LDS).
 __device__ __forceinline__ unsigned pair_screen32(const float *X, const float *Y, float px, float py, float thr)
 {
@@ -1180,7 +1188,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     }
     STAMP(4);
     {
-        // single-precision screening pass (see cell_pass_fast for the error argument)
+        // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest
+        // s32 is tracked (two cells per v_min3_u32); which cell it belongs to, and whether another cell is too
+        // close to tell in single precision, is settled in P4 by screening the one word that holds it once more.
         unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;   // ambw: words with an undecided sensed bit
         unsigned *wkey = reinterpret_cast<unsigned *>(L.sel);       // [64][MW], aliases the slot lists (written later)
         const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         // wave 0 also runs the k-NN pass above, so it takes only the first W0 words; the others share the rest
         const int W0 = T == 1 ? W : (W / T > ASM_W0_LESS ? W / T - ASM_W0_LESS : 0);
         for (int w = (T == 1 || sub == 0) ? 0 : W0 + sub - 1; w < ((T == 1 || sub != 0) ? W : W0); w += (T == 1 || sub == 0) ? 1 : T - 1) {
-            unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
+            unsigned k1 = 0xFFFFFFFFu, word = 0, ocand = 0;
             float amb = __builtin_inff(), ambo = __builtin_inff();
             const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
             const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
@@ -1200,13 +1210,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
                 const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
                 const float ss[4] = {sa.x, sa.y, sb.x, sb.y};
+                k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));   // s >= 0: the bit patterns order like the values
+                k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int b = q * 4 + r;
                     const float s = ss[r];
-                    const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)b;
-                    k2 = umed3(k1, k2, key);
-                    k1 = k1 < key ? k1 : key;
                     const f32x2 s2 = {s, s};
                     const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half)
                     word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
@@ -1216,12 +1224,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 }
             }
             L.mask[(size_t)l * MW + w] = __brev(word);
-            wkey[(size_t)l * MW + w] = k1;                           // smallest key of the word, for the rare tie resolution
+            wkey[(size_t)l * MW + w] = k1;                           // smallest s32 of the word
             if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
             settle_occupancy(P, active, __brev(ocand), ambo, px, py, gxe + w * 32, gye + w * 32, &occ_e[w], &cov_e[w]);
-            if (k1 < G1) G1w = (unsigned)w;
-            const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
-            G2 = m < t ? m : t;
+            if (k1 < G1) G1w = (unsigned)w;                         // strict: the first word holding the smallest s32
+            G2 = umed3(G1, G2, k1);                                 // the two smallest word minima
             G1 = G1 < k1 ? G1 : k1;
         }
         L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, ambw);
@@ -1243,21 +1250,48 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             G1 = G1 < q.x ? G1 : q.x;
             ambw |= q.w;
         }
-        int imin = (int)(G1w * 32 + (G1 & 31u));
-        double smin;
+        int imin = 0;
+        double smin = __builtin_inf();
         if (active) {
-            const bool amb_min = !((G2 >> 5) - (G1 >> 5) >= 2u);
-            if (amb_min) {                                          // words holding a candidate for the minimum
+            // Candidates for the nearest cell: s32 within two units of 32 ulps of the smallest one (the screen's error
+            // is a few ulps).  They lie in the word of the smallest s32 and, rarely, in other words whose minimum is
+            // that close.  Those words are screened again (same arithmetic, so the same s32) and the candidates
+            // evaluated in double; ascending index + strict '<' gives the reference's first minimum (CPP:889).
+            const unsigned lo = G1 >> 5;
+            unsigned minw = 1u << G1w;
+            if (!((G2 >> 5) - lo >= 2u)) {
                 const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
-                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - (G1 >> 5) < 2u) ambw |= 1u << w;
+                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
+            }
+            const unsigned lim = (lo << 5) + 64u;                   // candidate <=> bits(s32) < lim
+            const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+            while (minw) {
+                const int w = __ffs(minw) - 1; minw &= minw - 1;
+                const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
+                const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
+                unsigned cand = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 x4 = X[q], y4 = Y[q];
+                    const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                    const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                    const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                    const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.x) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.y) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.x) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.y) - lim, 31);
+                }
+                cand = __brev(cand);
+                while (cand) {
+                    const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
+                    const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
+                    const double sd = dx * dx + dy * dy;
+                    if (sd < smin) { smin = sd; imin = c; }
+                }
             }
             if (ambw) {
-                // Rare.  Re-run the fp32 screen on the flagged words (same arithmetic, so the same s32) and
-                // evaluate exactly only the cells the screen could not decide: those within the margin of
-                // T_sen, and the candidates for the minimum (truncated key within 2 units of the smallest;
-                // ascending index + strict '<' gives the reference's first minimum, CPP:889).
-                double best = __builtin_inf(); int besti = imin;
-                const unsigned lo = G1 >> 5;
+                // Rare: sensed bits within the margin of T_sen, decided in double
                 unsigned *mw = L.mask + (size_t)l * MW;
                 while (ambw) {
                     const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
@@ -1267,20 +1301,15 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                         const int c = w * 32 + b;
                         const float rx = gxe[c] - pxf, ry = gye[c] - pyf;
                         const float s32 = __builtin_fmaf(ry, ry, rx * rx);
-                        const bool a = __builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f;
-                        const bool m = amb_min && ((__float_as_uint(s32) >> 5) - lo < 2u);
-                        if (a || m) {
+                        if (__builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f) {
                             const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
                             const double sd = dx * dx + dy * dy;
-                            if (a) { if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b); }
-                            if (m && sd < best) { best = sd; besti = c; }
+                            if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b);
                         }
                     }
                     mw[w] = word;
                 }
-                if (amb_min) imin = besti;
             }
-            { const double rx = (double)gxe[imin] - px, ry = (double)gye[imin] - py; smin = rx * rx + ry * ry; }
             dmin = sqrt(smin);
             const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;     // CPP:894
             L.fin[l] = (unsigned)imin | (in_flag ? 0x80000000u : 0u);
