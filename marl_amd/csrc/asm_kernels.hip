@@ -426,11 +426,13 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
     double nn_min = __builtin_inf();
     if (active) {
-        auto consider = [&](int j, double s) {                           // sorted insert, ties keep the lower index
-            double ks = s; int kj = j;
+        // sorted insert; j arrives in ascending order, so an equal distance already listed stays in front (ties keep
+        // the lower index), and once the new entry is placed everything behind it moves down one place
+        auto consider = [&](int j, double s) {
+            double ks = s; int kj = j; bool placed = false;
 #pragma unroll
             for (int q = 0; q < 6; ++q)
-                if (ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+                if (placed || ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
         };
         if (swarm) {
             if constexpr (F32) {
@@ -1157,10 +1159,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
             const double s = dx * dx + dy * dy;                     // CPP:641
             if (s < P.T_sen) {                                      // CPP:663; self removed CPP:677-681
-                double ks = s; int kj = j;
+                double ks = s; int kj = j; bool placed = false;     // once placed, the entries behind move down one place
 #pragma unroll
                 for (int q = 0; q < 6; ++q)
-                    if (ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; }
+                    if (placed || ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
             }
         }
         if (P.want_stats && n_a > 1) {

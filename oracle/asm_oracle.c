@@ -86,6 +86,7 @@ void oracle_get_observation(double *p, double *dp, double *heading, double *obs,
     const double half_h = (boundary_pos[1] - boundary_pos[3]) / 2.0;   /* CPP:76 */
 
     double *norm_a = (double *)malloc(sizeof(double) * (size_t)n_a);
+    double *sq_a = (double *)malloc(sizeof(double) * (size_t)n_a);
     double *rel = (double *)malloc(sizeof(double) * 2 * (size_t)n_a);
     int *order = (int *)malloc(sizeof(int) * (size_t)n_a);
     double *norm_g = (double *)malloc(sizeof(double) * (size_t)(n_g > 0 ? n_g : 1));
@@ -106,14 +107,19 @@ void oracle_get_observation(double *p, double *dp, double *heading, double *obs,
             double rx = p[j] - px, ry = p[n_a + j] - py;
             if (is_periodic) wrap_rel(&rx, &ry, half_w, half_h);
             rel[j] = rx; rel[n_a + j] = ry;
-            norm_a[j] = sqrt(rx * rx + ry * ry);                   /* CPP:641 */
+            sq_a[j] = rx * rx + ry * ry;
+            norm_a[j] = sqrt(sq_a[j]);                             /* CPP:641 */
             order[j] = j;
         }
         /* sort by norm ascending (CPP:646).  std::sort leaves the order of equal norms
-         * unspecified; here ties go to the lower index (insertion sort, stable). */
+         * unspecified (what the compiled reference returns for them is an artefact of
+         * libstdc++'s introsort and depends on all n_a norms); here equal norms are ordered by
+         * the squared norm and then by the lower index, i.e. the list is sorted by (squared
+         * norm, index) -- the same order as by norm wherever the norms differ (insertion sort,
+         * stable). */
         for (int a = 1; a < n_a; ++a) {
             int v = order[a]; int b = a - 1;
-            while (b >= 0 && norm_a[order[b]] > norm_a[v]) { order[b + 1] = order[b]; --b; }
+            while (b >= 0 && sq_a[order[b]] > sq_a[v]) { order[b + 1] = order[b]; --b; }
             order[b + 1] = v;
         }
         /* keep norm < d_sen (CPP:663,672), drop the first kept (remove_self, CPP:677-681),
@@ -218,7 +224,7 @@ void oracle_get_observation(double *p, double *dp, double *heading, double *obs,
             col[(base + 4) * n_a] = heading[i]; col[(base + 5) * n_a] = heading[n_a + i];
         }
     }
-    free(norm_a); free(rel); free(order); free(norm_g); free(sensed); free(sensed0); free(occupied);
+    free(norm_a); free(sq_a); free(rel); free(order); free(norm_g); free(sensed); free(sensed0); free(occupied);
 }
 
 /* ------------------------------------------------------------------------- */

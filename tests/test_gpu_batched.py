@@ -350,3 +350,80 @@ def test_stream_shards_are_the_same_environments(torch_cuda):
         for j in (0, 1, 4):
             assert torch.equal(r1[j], torch.cat([r[j] for r in r2]))
     assert torch.allclose(one.episode_stats(), two.episode_stats(), rtol=1e-12, atol=0)
+
+
+def test_nearest_cell_exact_ties(torch_cuda):
+    """Agents exactly half way between two cells of a row (and at the centre of four): the distances tie in
+    double precision and the reference keeps the first minimum (np.argmin / AssemblyEnv.cpp:889)."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation
+    E, n_a = 7, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=1, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(8)
+    p = env.p.cpu().numpy()
+    n_tied = 0
+    for e in range(E):
+        env.set_shape(e, torch.tensor([e]))
+        g = env.grid_center[e].cpu().numpy()[:, :env.n_gs[e]].astype(np.float64)
+        found = []
+        for c in rng.permutation(env.n_gs[e] - 1):
+            for d in (1, 2):                                    # neighbour in the row, and the one after it
+                if c + d >= env.n_gs[e] or g[1, c] != g[1, c + d]:
+                    continue
+                mx = np.float32((g[0, c] + g[0, c + d]) / 2)
+                for my in (np.float32(g[1, c]), np.float32(g[1, c] + 0.01)):
+                    s = (g[0] - float(mx)) ** 2 + (g[1] - float(my)) ** 2
+                    if s[c] == s[c + d] and (d == 1 and s.min() == s[c]):
+                        found.append((mx, my, c))
+            if len(found) >= n_a:
+                break
+        assert len(found) >= n_a // 2, "shape offers too few exactly representable midpoints"
+        for i, (mx, my, c) in enumerate(found[:n_a]):
+            p[e, 0, i] = mx; p[e, 1, i] = my
+        n_tied += min(len(found), n_a)
+    env.p.copy_(torch.from_numpy(p))
+    env.observe(want_reward=True)
+    check_observation(env, cfg, True, "ties")
+    near = env.nearest_cell.cpu().numpy()
+    pd = env.p.cpu().numpy().astype(np.float64); gd = env.grid_center.cpu().numpy().astype(np.float64)
+    for e in range(E):
+        n_g = env.n_gs[e]
+        s = (gd[e, 0, None, :n_g] - pd[e, 0, :, None]) ** 2 + (gd[e, 1, None, :n_g] - pd[e, 1, :, None]) ** 2
+        assert np.array_equal(near[e], np.argmin(np.sqrt(s), axis=1)), f"env {e}"
+        ties = (np.sort(s, axis=1)[:, 0] == np.sort(s, axis=1)[:, 1]).sum()
+        assert ties >= n_a // 2
+    # the step kernel on the same state (zero action, zero velocity: the agents stay put)
+    env.dp.zero_()
+    env.step(torch.zeros(E, 2, n_a, device="cuda"))
+    moved = np.abs(env.p.cpu().numpy() - p).max()
+    if moved == 0:
+        assert np.array_equal(env.nearest_cell.cpu().numpy(), near)
+
+
+def test_equidistant_neighbours_keep_index_order(torch_cuda):
+    """Two neighbours at exactly the same distance, and a closer one with a higher index that is inserted after
+    them: the list stays ordered by (squared distance, index).  (The reference's std::sort leaves the order
+    of equal norms unspecified; the oracle defines it.)"""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation
+    n_a = 30
+    env = BatchedAssemblyEnv(3, n_a, seed=1, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    p = np.zeros((2, n_a)); p[0] = np.linspace(-2.3, 2.3, n_a); p[1] = 2.0
+    P = np.array([np.float32(-0.74249387), np.float32(0.27645427)], dtype=np.float64)
+    d = float(np.float32(0.27645427) - np.float32(0.21534318))
+    p[:, 25] = P; p[:, 11] = P + [0, -d]; p[:, 19] = P + [-d, 0]; p[:, 24] = P + [0, -0.01]
+    p[:, 3] = P + [d, 0]; p[:, 28] = P + [0, d]; p[:, 7] = P + [0.02, 0]; p[:, 29] = P + [-0.02, 0]
+    p = p.astype(np.float32)
+    env.p.copy_(torch.from_numpy(np.stack([p, p[:, ::-1].copy(), p])))
+    env.dp.zero_()
+    env.observe(want_reward=True)
+    check_observation(env, cfg, True, "equidistant observe")
+    assert env.neighbor_index[0, 25].cpu().tolist() == [24, 7, 29, 3, 11, 19]
+    env.step(torch.zeros(3, 2, n_a, device="cuda"))            # agents that touch are pushed; the check is against the oracle
+    check_observation(env, cfg, True, "equidistant step")

@@ -98,3 +98,19 @@ def test_batch_reset_ranges_and_determinism():
     assert np.allclose(np.linalg.norm(ge[:, 1:] - ge[:, :-1], axis=0), np.linalg.norm(g0[1:] - g0[:-1], axis=1), atol=1e-12)
     c = ol.batch_reset(226, 1, 0, 8, 30, grids, l_cells, 544)
     assert not np.array_equal(c[1], p[:8])
+
+
+def test_oracle_orders_equal_norms_by_index():
+    """std::sort (AssemblyEnv.cpp:646) leaves the order of equal norms unspecified; the oracle lists them by
+    (squared norm, index)."""
+    import oracle_lib as ol
+    n_a = 30
+    p = np.zeros((2, n_a)); p[0] = np.linspace(-2.3, 2.3, n_a); p[1] = 2.0
+    P = np.array([np.float32(-0.74249387), np.float32(0.27645427)], dtype=np.float64)
+    d = float(np.float32(0.27645427) - np.float32(0.21534318))
+    p[:, 25] = P; p[:, 11] = P + [0, -d]; p[:, 19] = P + [-d, 0]; p[:, 24] = P + [0, -0.01]
+    p = np.ascontiguousarray(p.astype(np.float32).astype(np.float64))
+    grid = np.ascontiguousarray(np.random.default_rng(0).uniform(-1, 1, (2, 100)))
+    o = ol.oracle_fns().get_observation(p, np.zeros((2, n_a)), np.zeros((2, n_a)), np.array([-2.4, 2.4, 2.4, -2.4]),
+                                        grid, 0.4, 0.26, 0.06)
+    assert o[1][25].tolist() == [24, 11, 19, -1, -1, -1]
