@@ -1379,18 +1379,22 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 wq |= (unsigned)wi << (5 * q);
             }
             unsigned bits = fq[0];
-            while (busy) {
-                const int b = __ffs(bits) - 1; bits &= bits - 1;
-                mysel[rank++] = (unsigned short)((wq & 31u) * 32 + b);
+            busy = busy && bits != 0;
+            unsigned short *wp = mysel + rank, *const wend = mysel + k1;
+            unsigned wbase = (wq & 31u) << 5;
+            while (busy) {                                          // bits != 0 here
+                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
+                *wp++ = (unsigned short)(wbase | b);
                 ++diag_it;
                 if (bits == 0) {
 #pragma unroll
                     for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
-                    fq[QN - 1] = 0; wq >>= 5;
+                    fq[QN - 1] = 0; wq >>= 5; wbase = (wq & 31u) << 5;
                     bits = fq[0];
-                    if (bits == 0 || rank >= k1) busy = false;
+                    if (bits == 0 || wp >= wend) busy = false;
                 }
             }
+            rank = (int)(wp - mysel);
             busy = found && rank < k1 && nz != 0;                   // rare: more than QN words in this wave's range
             bits = 0;
             int w = 0;
