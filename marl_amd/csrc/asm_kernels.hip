@@ -29,6 +29,15 @@ namespace asmenv {
 
 #define ASM_PI 3.14159265358979323846
 
+// Phase accounting build (make exits; tools/phase_valu.sh): the step kernel returns at the phase boundary
+// named by MARL_AMD_DBG_EXIT, so that counter differences between runs give per-phase instruction counts.
+#ifdef ASM_EXITS
+__device__ int g_exit_at = 0;
+#define EXIT_AT(k) do { if (xat == (k)) return; } while (0)
+#else
+#define EXIT_AT(k) do { } while (0)
+#endif
+
 // Diagnostic build only (make diag): cycle stamps at phase boundaries, written by lane 0
 // of each workgroup's first wave to a buffer of its own.  The product build has no stamps.
 #ifdef ASM_DIAG
@@ -912,7 +921,8 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
 // T is chosen by the host so that a launch has enough waves to fill the chip.
 struct FastLds {
     float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
-    float *g;                      // [2][2][NGP]  per env: x row, y row; cells >= n_g hold 1e30
+    float *g;                      // x rows of the two environments at [0, 2 NGP), their y rows ASM_GY_OFF floats further on
+                                   // (a compile-time distance: one address serves both coordinates of a cell); cells >= n_g hold 1e30
     unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
     unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
     uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
@@ -921,13 +931,15 @@ struct FastLds {
     unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
 };
 
+#define ASM_GY_OFF 2048      // floats between a cell's x and y in LDS (>= 2 * 1024 cells)
+
 __device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T)
 {
     FastLds L;
     float *f = reinterpret_cast<float *>(smem);
     L.px = f; L.py = f + 64; L.vx = f + 128; L.vy = f + 192;
     L.g = f + 256;
-    L.mask = reinterpret_cast<unsigned *>(L.g + 4 * P.NGP);
+    L.mask = reinterpret_cast<unsigned *>(L.g + ASM_GY_OFF + 2 * P.NGP);
     L.occ = L.mask + 64 * P.MW;
     L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
     L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
@@ -985,11 +997,16 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
     const FastLds L = carve_fast(smem, P, T);
-    float *gxe = L.g + (size_t)es * 2 * NGP, *gye = gxe + NGP;
+    float *gxe = L.g + (size_t)es * NGP, *gye = gxe + ASM_GY_OFF;
     unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
     constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
     STAMP(0);
 
+#ifdef ASM_EXITS
+    const int xat = g_exit_at;
+#else
+    constexpr int xat = 0;
+#endif
     // ---- P0: grid and state into LDS (all global loads issued before the first LDS write) ----
     const int e0 = blockIdx.x * 2;
     const int ng0 = e0 < P.E ? ng_g[e0] : 0, ng1 = e0 + 1 < P.E ? ng_g[e0 + 1] : 0;
@@ -1007,7 +1024,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const int h = row >> 1, ngh = h ? ng1 : ng0;
             const bool row_ok = e0 + h < P.E;
             const float *src = grid_g + ((size_t)(e0 + h) * 2 + (row & 1)) * NGP;
-            float *dst = L.g + (size_t)row * NGP;
+            float *dst = L.g + (size_t)(row & 1) * ASM_GY_OFF + (size_t)h * NGP;
             for (int base = 0; base < NGP; base += 64 * 4 * 4) {
                 float4 v[4];
 #pragma unroll
@@ -1037,6 +1054,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     }
     __syncthreads();
     STAMP(1);
+    EXIT_AT(1);
 
     // ---- P1: forces, prior and integration on the OLD state (ENV:486-647) -------------
     float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
@@ -1119,6 +1137,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     }
     __syncthreads();
     STAMP(3);
+    EXIT_AT(2);
 
     // ---- P3: agent x cell pass on the NEW state, words split over the waves ------------
     const float pxf = L.px[l], pyf = L.py[l];
@@ -1136,7 +1155,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #pragma unroll
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
     double nn_min = __builtin_inf();
-    if (sub == 0 && active) {
+    if (sub == 0 && active && xat != 13) {
         // k nearest neighbours inside d_sen (_get_focused, CPP:633-703): fp32 screen, exact on candidates
         unsigned cand = 0, n1 = 0xFFFFFFFFu, n2 = 0xFFFFFFFFu;
 #pragma unroll
@@ -1238,6 +1257,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(5);
     __syncthreads();
     STAMP(12);
+    EXIT_AT(3);
 
     // ---- P4 (wave 0): nearest cell, in-shape flag, target block -------------------------
     double dmin = 0.0;
@@ -1329,6 +1349,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(13);
     __syncthreads();
     STAMP(14);
+    EXIT_AT(4);
 
     // ---- P5: compaction of the sensed lists into LDS -----------------------------------
     const unsigned fin = L.fin[l];
@@ -1452,6 +1473,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(6);
     if (T > 1) __syncthreads();                                     // the lists are complete
     STAMP(15);
+    EXIT_AT(5);
 
     // ---- P6: the observation's cell block (CPP:279-296) + reward weights, slots split over the waves ----
     const bool rew_on = active && in_flag && n_after > 0;
@@ -1464,7 +1486,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             for (int kb = k0; kb < k1; kb += RB) {
                 int cell[RB]; float cx[RB], cy[RB]; bool have[RB];
 #pragma unroll
-                for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q < k1 ? kb + q : k1 - 1];   // unconditional: one batch of LDS reads
+                for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q];   // one batch of LDS reads; entries past k1 (the list is padded by RB) are masked below
 #pragma unroll
                 for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? cell[q] : 0; }
 #pragma unroll
@@ -1480,7 +1502,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                         if (sdst) sdst[k] = have[q] ? cell[q] : -1;
                         // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
                         const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
-                        const float psi = have[q] ? 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f) : 0.f;
+                        const float psi = have[q] ? __builtin_fmaf(0.5f, __builtin_amdgcn_cosf(z * P.inv2dsen_f), 0.5f) : 0.f;
                         fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
                     }
                 }
@@ -1490,6 +1512,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     }
     STAMP(7);
     if (T > 1) __syncthreads();
+    EXIT_AT(6);
 
     // ---- P7 (wave 0): reward (CPP:457-564) and per-environment statistics ---------------
     if (sub == 0) {
@@ -1534,7 +1557,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const double sx = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pxf), src));
             const double sy = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pyf), src));
             const unsigned short *ssel = L.sel + (size_t)src * P.capp;
-            const float *sgx = L.g + (size_t)(src >> 5) * 2 * NGP, *sgy = sgx + NGP;
+            const float *sgx = L.g + (size_t)(src >> 5) * NGP, *sgy = sgx + ASM_GY_OFF;
             double num0 = 0.0, num1 = 0.0, den = 0.0;
             for (int k = l; k < n_src; k += 64) {
                 const int cell = ssel[k];
@@ -1961,6 +1984,10 @@ int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, 
                      const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
                      int *sensed, int *occupied, double *stats, hipStream_t st)
 {
+#ifdef ASM_EXITS
+    { const char *x = std::getenv("MARL_AMD_DBG_EXIT"); const int v = x ? std::atoi(x) : 0;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
+#endif
     switch (P.fast_T) {
     case 1: return launch_step_fast_t<1>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
     case 2: return launch_step_fast_t<2>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);

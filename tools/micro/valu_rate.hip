@@ -29,6 +29,12 @@ __global__ void k(unsigned *out, int iters, unsigned seed)
             if (KIND == 9) d[q] = d[q] < d[(q + 1) & 7] ? d[q] : d[(q + 1) & 7] + 1.0;   // v_cmp_f64 + 2 v_cndmask + v_add_f64
             if (KIND == 10) d[q] = 1.0 / d[q] + 1.5;                         // double division sequence
             if (KIND == 11) d[q] = sqrt(d[q]) + 2.0;                         // double sqrt sequence
+            if (KIND == 12) p[q].x = __builtin_amdgcn_sqrtf(p[q].x);         // v_sqrt_f32
+            if (KIND == 13) p[q].x = __builtin_amdgcn_cosf(p[q].x);          // v_cos_f32
+            if (KIND == 14) p[q].x = __builtin_amdgcn_rcpf(p[q].x);          // v_rcp_f32
+            if (KIND == 15) asm volatile("v_min3_u32 %0, %1, %2, %3" : "=v"(a[q]) : "v"(a[q]), "v"(a[(q + 1) & 7]), "v"(seed));
+            if (KIND == 16) asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a[q]) : "v"(a[(q + 1) & 7]), "v"(a[q]));
+            if (KIND == 17) a[q] = (unsigned)__builtin_ctz(a[q] | 256u) + a[(q + 1) & 7];   // v_ffbl_b32 (+ or, add)
         }
     }
     unsigned r = 0;
@@ -61,5 +67,7 @@ int main()
     run<0>("v_alignbit"); run<1>("v_med3_u32"); run<2>("v_min_u32"); run<3>("v_pk_fma_f32"); run<4>("v_pk_add_f32");
     run<5>("v_and_or_b32"); run<6>("v_fma_f32"); run<7>("v_fma_f64"); run<8>("v_add_f64"); run<9>("f64 cmp+sel+add");
     run<10>("f64 1/x + add"); run<11>("f64 sqrt + add");
+    run<12>("v_sqrt_f32"); run<13>("v_cos_f32"); run<14>("v_rcp_f32"); run<15>("v_min3_u32"); run<16>("v_bcnt_u32_b32");
+    run<17>("ffbl+or+add");
     return 0;
 }
