@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--agents", type=int, default=30)
+    ap.add_argument("--graph-steps", type=int, default=0,
+                    help="steps per captured HIP graph (must divide the episode length of 200; 0 = launch every step from the host)")
     ap.add_argument("--streams", type=int, default=2,
                     help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,7 +158,8 @@ def main():
             env.observe()
 
     shards.on_each(lambda k, env: reset_one(k, env, 0))
-    ring = min(max(K, 1), 64)
+    C = args.graph_steps if args.graph_steps > 0 and EPISODE_LENGTH % args.graph_steps == 0 else 0
+    ring = min(max(K, 1), 64) if C == 0 else next(r for r in range(min(C, 64), 0, -1) if C % r == 0)
 
     def draw_actions(k, env):
         a = torch.empty(ring, env.E, 2, n_a, dtype=torch.float32, device=device)
@@ -166,19 +169,43 @@ def main():
 
     actions = shards.on_each(draw_actions)
     n_g_mean = float(torch.cat(shards.on_each(lambda k, env: env.n_g.double())).mean())
-    totals = torch.zeros(8, dtype=torch.float64, device=device)
+    totals = torch.zeros(S, 8, dtype=torch.float64, device=device)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n, t0=0):
-        for t in range(t0, t0 + n):
+    # C consecutive steps recorded into one HIP graph over the shard streams (the step allocates nothing and never
+    # synchronises): one host launch per C steps.  Episode ends (statistics all-reduce, reset) stay outside.
+    graph = None
+    if C:
+        for t in range(3):                                    # lazy kernel loading must not happen under capture
             shards.step([a[t % ring] for a in actions])
-            if (t + 1) % EPISODE_LENGTH == 0:               # end of episode (TRAIN:99,107,177-197)
-                totals.add_(reduce_episode_stats(shards.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
-                shards.on_each(reset_one)
+        shards.on_each(lambda k, env: reset_one(k, env, 0))
+        graph = shards.capture(lambda: [shards.step([a[t % ring] for a in actions]) for t in range(C)])
+
+    # Shard k's episodes end at steps = -phase[k] (mod 200): the shards take turns, so one shard's statistics
+    # all-reduce and reset run under the other shards' step kernels instead of leaving the chip idle.  With graphs
+    # every shard ends at the graph boundary.  (Shard k > 0 therefore starts with a shortened first episode.)
+    phase = [0 if C else k * EPISODE_LENGTH // S for k in range(S)]
+
+    def episode_end(k, env):                                # on shard k's stream
+        totals[k].add_(reduce_episode_stats(env.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
+        reset_one(k, env)
+
+    def run_steps(n, t0=0):
+        t, end = t0, t0 + n
+        while t < end:
+            if graph is not None and t % C == 0 and end - t >= C:   # C divides the episode length: no episode end inside
+                graph.replay()
+                t += C
+            else:
+                shards.step([a[t % ring] for a in actions])
+                t += 1
+            for k in range(S):                              # end of shard k's episode (TRAIN:99,107,177-197)
+                if (t + phase[k]) % EPISODE_LENGTH == 0:
+                    shards.on_each(episode_end, only=k)
 
     # untimed: W warm-up steps, plus one pass through the episode-boundary path so that
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
@@ -186,7 +213,9 @@ def main():
     mark("environment reset, actions drawn")
     run_steps(W)
     mark("warm-up steps done")
-    totals.add_(reduce_episode_stats(shards.episode_stats())).zero_()
+    shards.on_each(lambda k, env: totals[k].add_(reduce_episode_stats(env.episode_stats())))
+    shards.synchronize()
+    totals.zero_()
     mark("warm-up all-reduce done")
     barrier()
     mark("barrier passed, timing")
@@ -228,7 +257,7 @@ def main():
                        "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
                        "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,
                        "state": "float32 in HBM; decisions evaluated in float64",
-                       "streams_per_gpu": S,
+                       "streams_per_gpu": S, "steps_per_hip_graph": C,
                        "parallelism": f"env-sharded x{world} GPUs x{S} HIP streams, RCCL all-reduce of 8 doubles per episode"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

@@ -220,9 +220,17 @@ int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const fl
     if (!p || !dp || !grid || !n_g || !l_cell || !neighbor_index || !in_flags || !nearest_cell || !obs)
         return fail(1, "asm_batch_observe_f32: NULL required pointer");
     P.want_reward = reward != nullptr;
-    int rc = asmenv::launch_observe<float>(P, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags,
+    int rc;
+    if (P.fast_T) {                                                 // the step kernel without its dynamics phase
+        P.observe_only = 1; P.prior = 0;
+        rc = asmenv::launch_step_fast(P, const_cast<float *>(p), const_cast<float *>(dp), nullptr, grid, n_g, l_cell,
+                                      neighbor_index, in_flags, nearest_cell, obs, reward, nullptr, sensed_index,
+                                      occupied_index, nullptr, (hipStream_t)stream);
+    } else {
+        rc = asmenv::launch_observe<float>(P, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags,
                                            nearest_cell, obs, reward, sensed_index, occupied_index,
                                            (hipStream_t)stream);
+    }
     return rc ? hip_fail(rc, "asm_batch_observe_f32") : 0;
 }
 
@@ -257,9 +265,15 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
     if (!shape_grids || !shape_off || !shape_ng || !shape_lcell || !shape_id || !p || !dp || !grid || !n_g || !l_cell ||
         !neighbor_index || !in_flags || !nearest_cell || !obs)
         return fail(1, "asm_batch_reset_f32: NULL required pointer");
+    P.state_only = P.fast_T != 0;                                   // then the step kernel observes the new state
     int rc = asmenv::launch_reset<float>(P, seed, episode, env0, n_shapes, shape_grids, shape_off, shape_ng,
                                          shape_lcell, shape_id, p, dp, grid, n_g, l_cell, neighbor_index, in_flags,
                                          nearest_cell, obs, sensed_index, occupied_index, (hipStream_t)stream);
+    if (!rc && P.fast_T) {
+        P.observe_only = 1; P.prior = 0; P.want_reward = 0; P.want_stats = 0;
+        rc = asmenv::launch_step_fast(P, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+                                      nullptr, nullptr, sensed_index, occupied_index, nullptr, (hipStream_t)stream);
+    }
     return rc ? hip_fail(rc, "asm_batch_reset_f32") : 0;
 }
 

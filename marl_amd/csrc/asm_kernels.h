@@ -16,6 +16,8 @@ struct DevParams {
     int E, n_a, SL, EPB, n_g_max, NGP, W, MW;
     int topo, n_obs, n_occ, obs_dim;
     int periodic, cartesian, con_self, prior, recompute, want_reward, want_stats;
+    int observe_only;               // k_step_fast: no dynamics, the state is observed as it is (reset, observe)
+    int state_only;                 // k_reset: draw the state and the grid only; the observation comes from another launch
     int n_g_e;                      // set per environment inside the kernels
     int block, grid;
     unsigned lds_env_bytes, lds_block_bytes;

@@ -1056,9 +1056,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(1);
     EXIT_AT(1);
 
-    // ---- P1: forces, prior and integration on the OLD state (ENV:486-647) -------------
-    float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
     int contacts = 0;
+    if (!P.observe_only) {                                          // reset / observe: the state is taken as it is
+    float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
+    // ---- P1: forces, prior and integration on the OLD state (ENV:486-647) -------------
     if (sub == 0 && active) {
         const float pxf = L.px[l], pyf = L.py[l];
         const double px = pxf, py = pyf, vx = L.vx[l], vy = L.vy[l];
@@ -1136,6 +1137,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         p_g[o + i] = npx; p_g[o + n_a + i] = npy; dp_g[o + i] = nvx; dp_g[o + n_a + i] = nvy;
     }
     __syncthreads();
+    }
     STAMP(3);
     EXIT_AT(2);
 
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         if (active) {
             if (in_flag && !collision && uniform) reward += 1.0;    // CPP:559-561
-            rew_g[(size_t)e * n_a + i] = (float)reward;
+            if (P.want_reward) rew_g[(size_t)e * n_a + i] = (float)reward;
         }
         STAMP(8);
         if (P.want_stats) {                                         // TRAIN:128-135; WRAP:48-165
@@ -1682,6 +1684,7 @@ __global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t en
     } else {
         for (int c = i; c < P.NGP; c += P.SL) { L.gx[c] = (S)1e30; L.gy[c] = (S)1e30; }
     }
+    if (P.state_only) return;                                       // the caller observes the new state with k_step_fast
     __syncthreads();
     DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0; Q.want_reward = 0;
     observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, nullptr, sensed_g, occup_g,

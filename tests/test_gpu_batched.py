@@ -427,3 +427,30 @@ def test_equidistant_neighbours_keep_index_order(torch_cuda):
     assert env.neighbor_index[0, 25].cpu().tolist() == [24, 7, 29, 3, 11, 19]
     env.step(torch.zeros(3, 2, n_a, device="cuda"))            # agents that touch are pushed; the check is against the oracle
     check_observation(env, cfg, True, "equidistant step")
+
+
+def test_captured_steps_equal_eager_steps(torch_cuda):
+    """StreamShards.capture: a HIP graph of several steps over the shard streams leaves exactly the state,
+    observations and statistics of the same steps launched one by one; replays and eager steps can alternate."""
+    torch = torch_cuda
+    from marl_amd.sharding import StreamShards
+    E, n_a, G = 50, 30, 6
+    a_sh = StreamShards(E, n_a, parts=2, seed=4)
+    b_sh = StreamShards(E, n_a, parts=2, seed=4)
+    a_sh.reset(0); b_sh.reset(0)
+    acts = a_sh.on_each(lambda k, env: torch.stack([env.random_actions(step=j) for j in range(G)]))
+    a_sh.step([a[0] for a in acts]); b_sh.step([a[0] for a in acts])          # kernels loaded before the capture
+    graph = a_sh.capture(lambda: [a_sh.step([a[j] for a in acts]) for j in range(G)])
+    assert a_sh.envs[0].step_count == 1                                      # capturing ran nothing
+    for rnd in range(2):
+        graph.replay()
+        a_sh.step([a[1] for a in acts])                                      # eager work queued behind the replay
+        for j in range(G):
+            b_sh.step([a[j] for a in acts])
+        b_sh.step([a[1] for a in acts])
+    a_sh.synchronize(); b_sh.synchronize(); torch.cuda.synchronize()
+    assert a_sh.envs[0].step_count == b_sh.envs[0].step_count == 1 + 2 * (G + 1)
+    for ea, eb in zip(a_sh.envs, b_sh.envs):
+        for name in ("p", "dp", "obs", "reward", "a_prior", "neighbor_index", "in_flags", "stats"):
+            assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+    assert torch.equal(a_sh.episode_stats(), b_sh.episode_stats())
