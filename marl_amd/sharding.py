@@ -52,7 +52,7 @@ class StreamShards:
 
     A single launch over all environments leaves the chip part-empty while its workgroups ramp up and
     while the last ones drain; with two launches in flight, one shard's ramp and tail run under the other
-    shard's steady state (4096 environments on one MI355X: 72 -> 55 us per step of the whole batch).
+    shard's steady state (4096 environments on one MI355X: 58 -> 46 us per step of the whole batch).
     The shards own contiguous global environment ids, so together they are exactly the environments of
     one BatchedAssemblyEnv(num_envs, env_id_offset=...).  Each shard is driven on its stream; nothing
     orders the shards against each other until synchronize() or episode_stats().
@@ -96,8 +96,7 @@ class StreamShards:
     def capture(self, fn) -> "ShardGraph":
         """Record fn() -- any sequence of step()/on_each() calls whose tensors stay alive -- into one HIP graph
         that spans the shard streams.  Replaying it costs one launch on the host instead of one per shard and
-        step, and the device runs the recorded launches back to back (4096 environments on one MI355X:
-        46.4 -> 44.1 us per step).  The environment step allocates nothing and never synchronises, so it can
+        step (with two shards of 2048 environments the host keeps up anyway and a replay runs at the same speed).  The environment step allocates nothing and never synchronises, so it can
         be captured as it is."""
         cur = torch.cuda.current_stream(self.device)
         cap = torch.cuda.Stream(device=self.device)
