@@ -1443,23 +1443,31 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
             const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
             const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
-            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0;
-            int rank = 0, k = k0, w = 0;
+            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0, wbase = 0;
+            // t_{k0} >= k0, and the words before word nb - 1 end below rank k0: the walk starts at word nb - 1,
+            // whose first rank is bst minus its own count
+            const int w0 = nb > 0 ? nb - 1 : 0;
+            int rank = nb > 0 ? bst - __popc(mym[w0] & ~(occ_e[w0] & inm)) : 0;
+            nz &= 0xFFFFFFFFu << w0;
+            unsigned short *wp = mysel + k0, *const wend = mysel + (k1 < n_out ? k1 : n_out);
             bool busy = active && k0 < n_out;
             while (busy) {
                 if (bits == 0) {
                     if (nz == 0) { busy = false; continue; }
-                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    const int w = __builtin_ctz(nz); nz &= nz - 1;
                     bits = mym[w] & ~(occ_e[w] & inm);
+                    wbase = (unsigned)w << 5;
                     const int pc = __popc(bits);
                     if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+                    for (int d = (int)tq - rank; d > 0; --d) bits &= bits - 1;             // so do its first tq - rank cells
+                    rank = rank < (int)tq ? (int)tq : rank;
                 }
-                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
                 if ((unsigned)rank == tq) {
-                    mysel[k] = (unsigned short)(w * 32 + b);
-                    ++k; tq += inc_q; tr += inc_r;
+                    *wp++ = (unsigned short)(wbase | b);
+                    tq += inc_q; tr += inc_r;
                     if (tr >= two_c) { tr -= two_c; ++tq; }
-                    if (k >= k1 || k >= n_out) busy = false;
+                    if (wp >= wend) busy = false;
                 }
                 ++rank;
             }
