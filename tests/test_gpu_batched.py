@@ -454,3 +454,39 @@ def test_captured_steps_equal_eager_steps(torch_cuda):
         for name in ("p", "dp", "obs", "reward", "a_prior", "neighbor_index", "in_flags", "stats"):
             assert torch.equal(getattr(ea, name), getattr(eb, name)), name
     assert torch.equal(a_sh.episode_stats(), b_sh.episode_stats())
+
+
+@pytest.mark.parametrize("n_a,step_denominator,fast_t", [(30, 64, "4"), (30, 16, "4"), (16, 32, "4"), (100, 32, "4"),
+                                                           (30, 64, "0"), (30, 16, "1"), (16, 32, "2")])
+def test_lattice_states_full_of_ties(torch_cuda, monkeypatch, n_a, step_denominator, fast_t):
+    """Agents snapped to a coarse binary lattice (distinct points): equal neighbour distances, equal distances to
+    cells of the unrotated shape and distances that hit thresholds' neighbourhoods are the rule here, not the
+    exception.  Observation and teacher-forced steps against the oracle, indices exact (fast_t: the kernel
+    schedule, "0" = the generic kernel)."""
+    torch = torch_cuda
+    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E = 12
+    env = BatchedAssemblyEnv(E, n_a, seed=31, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    for e in range(0, E, 2):
+        env.set_shape(e % env.num_train_shape, torch.tensor([e]))           # unrotated, centred: symmetric cell rows
+    rng = np.random.default_rng(step_denominator + n_a)
+    q = 1.0 / step_denominator
+    p = np.zeros((E, 2, n_a), np.float32)
+    for e in range(E):
+        half = 0.5 if e % 3 else 1.5                                        # dense clusters and spread-out swarms
+        m = int(round(half / q))
+        side = 2 * m + 1
+        pick = rng.choice(side * side, n_a, replace=False)                  # distinct lattice points
+        p[e, 0] = (pick % side - m) * q; p[e, 1] = (pick // side - m) * q
+    env.p.copy_(torch.from_numpy(p))
+    v = rng.integers(-2, 3, (E, 2, n_a)).astype(np.float32) * 0.25          # velocities on a lattice too
+    env.dp.copy_(torch.from_numpy(v))
+    env.observe(want_reward=True)
+    check_observation(env, cfg, True, "lattice observe")
+    for t in range(3):
+        act = rng.integers(-4, 5, (E, 2, n_a)).astype(np.float32) * 0.25
+        teacher_forced_step(env, cfg, act, f"lattice step {t}")

@@ -81,3 +81,29 @@ def test_walls_and_contacts_crowded_corner(hip):
     size = np.full(60, 0.035)
     a = hip.get_dist_b2w(p, size, BPOS); b = orc.get_dist_b2w(p, size, BPOS)
     assert a[1].sum() > 5 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_five_symbols_on_lattice_state(hip):
+    """Agents on a binary lattice (equal distances everywhere), true double inputs: every output of the five
+    entry points equals the oracle's, values included (no transcendental on this path except the reward's cos)."""
+    from marl_amd.shapes import load_shapes
+    orc = ol.oracle_fns()
+    l_cells, grids = load_shapes()
+    rng = np.random.default_rng(12)
+    for shape, n_a, q in ((0, 30, 1 / 16), (3, 30, 1 / 64), (5, 64, 1 / 32)):
+        grid = np.ascontiguousarray(np.asarray(grids[shape], dtype=np.float64).T); l_cell = float(l_cells[shape])
+        m = int(round(0.75 / q)); side = 2 * m + 1
+        pick = rng.choice(side * side, n_a, replace=False)
+        p = np.ascontiguousarray(np.stack([(pick % side - m) * q, (pick // side - m) * q]).astype(np.float64))
+        dp = np.ascontiguousarray(rng.integers(-2, 3, (2, n_a)) * 0.25); heading = np.zeros_like(p)
+        a = hip.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell)
+        b = orc.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell)
+        for name, x, y in zip(("obs", "nbr", "in_flags", "sensed", "occupied"), a, b):
+            assert np.array_equal(x, y), (shape, name)
+        obs, nbr, inf, sen, occ = b
+        ra = hip.get_reward(p, dp, heading, dp, BPOS, grid, nbr, inf, sen, occ, 0.4, 0.26, l_cell)
+        rb = orc.get_reward(p, dp, heading, dp, BPOS, grid, nbr, inf, sen, occ, 0.4, 0.26, l_cell)
+        assert np.array_equal(ra, rb), shape
+        dc, de, co = ol.get_dist_b2b(p)
+        assert np.array_equal(hip.sf_b2b_all(p, de, co, BPOS, dc), orc.sf_b2b_all(p, de, co, BPOS, dc))
+        assert np.array_equal(hip.prior(p, dp, grid, nbr, 0.4, 0.26, l_cell), orc.prior(p, dp, grid, nbr, 0.4, 0.26, l_cell))
