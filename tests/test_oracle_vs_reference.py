@@ -92,3 +92,35 @@ def test_run_envs_driver_matches_reference_binding():
     finally:
         ol.bind(None)
     assert s1 == s2 and np.array_equal(p1, p2) and np.array_equal(d1, d2)
+
+
+def test_lattice_state_against_reference_except_tie_order():
+    """Agents on a binary lattice: everything the reference specifies must agree -- in-shape flags, sensed and
+    occupied lists, nearest-cell blocks of the observation, rewards' inputs -- and the neighbour lists must hold
+    the same distances in the same order; only WHICH of several equidistant agents comes first may differ
+    (std::sort, AssemblyEnv.cpp:646, leaves that open; the oracle orders by squared distance, then index)."""
+    ref = ol.reference_fns(); orc = ol.oracle_fns()
+    from marl_amd.shapes import load_shapes
+    l_cells, grids = load_shapes()
+    rng = np.random.default_rng(3)
+    bpos = np.array([-2.4, 2.4, 2.4, -2.4])
+    tied_orders = 0
+    for shape, n_a, q in ((0, 30, 1 / 16), (3, 30, 1 / 64), (5, 64, 1 / 32), (6, 30, 1 / 8)):
+        grid = np.ascontiguousarray(np.asarray(grids[shape], dtype=np.float64).T); l_cell = float(l_cells[shape])
+        m = int(round(0.75 / q)); side = 2 * m + 1
+        pick = rng.choice(side * side, n_a, replace=False)
+        p = np.ascontiguousarray(np.stack([(pick % side - m) * q, (pick // side - m) * q]).astype(np.float64))
+        dp = np.ascontiguousarray(rng.integers(-2, 3, (2, n_a)) * 0.25); heading = np.zeros_like(p)
+        a = ref.get_observation(p, dp, heading, bpos, grid, 0.4, 0.26, l_cell)
+        b = orc.get_observation(p, dp, heading, bpos, grid, 0.4, 0.26, l_cell)
+        for name, x, y in zip(("in_flags", "sensed", "occupied"), a[2:], b[2:]):
+            assert np.array_equal(x, y), (shape, name)
+        assert np.array_equal(a[0][:4], b[0][:4]) and np.array_equal(a[0][28:], b[0][28:])     # own state, target + cell blocks
+        d = np.sqrt((p[0][None, :] - p[0][:, None]) ** 2 + (p[1][None, :] - p[1][:, None]) ** 2)
+        for i in range(n_a):
+            na, nb = a[1][i], b[1][i]
+            assert np.array_equal(na >= 0, nb >= 0)
+            k = int((na >= 0).sum())
+            assert np.array_equal(d[i, na[:k]], d[i, nb[:k]]), (shape, i)                      # same distances, same order
+            tied_orders += int(not np.array_equal(na, nb))
+    assert tied_orders > 0          # the state does exercise the unspecified case
