@@ -122,9 +122,9 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
         int T = 4;                                                   // fastest measured schedule at every batch size from 2048 to 32768 environments
         if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
         if (T == 1 || T == 2 || T == 4) {
-            // state 256 floats; grid: x rows of both environments, y rows 2048 floats further on; masks; occupancy;
+            // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on; masks; occupancy;
             // partials; flags; reward partials; slot lists (+ one emission round of padding) aliased with the word keys
-            const size_t bytes = 4 * (256 + 2048 + 2 * (size_t)P.NGP + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
+            const size_t bytes = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
                                  4 * 64 + 4 * 3 * 64 * (size_t)T + std::max(2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW);
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
         }

@@ -4,6 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// k_step_fast keeps a cell's y this many floats after its x in LDS (x rows of the two environments first), a
+// compile-time distance so that one address serves both; it must hold two rows of up to 1024 cells.
+#ifndef ASM_GY_OFF
+#define ASM_GY_OFF 2048
+#endif
+
 namespace asmenv {
 
 constexpr int ASM_MAX_AGENTS = 1024;   // largest n_a the entry points accept

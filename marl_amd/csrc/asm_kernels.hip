@@ -931,8 +931,6 @@ struct FastLds {
     unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
 };
 
-#define ASM_GY_OFF 2048      // floats between a cell's x and y in LDS (>= 2 * 1024 cells)
-
 __device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T)
 {
     FastLds L;
@@ -1001,6 +999,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
     constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
     STAMP(0);
+#ifdef ASM_DIAG
+    if (g_diag && l == 0) g_diag[(size_t)blockIdx.x * 32 + 20 + sub] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID of this wave
+#endif
 
 #ifdef ASM_EXITS
     const int xat = g_exit_at;
