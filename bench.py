@@ -271,6 +271,8 @@ def main():
                          "launches_in_flight": S, "achieved_per_launch": achieved / S,
                          "alg_bytes_per_launch": per_launch * b_alg,
                          "kernel": "k_step_fast / k_step (asm_batch_step_f32)", "avg_launch_ms": kern_ms,
+                         # avg_launch_ms: HIP events on each shard's stream around its K back-to-back launches, / K, i.e. the
+                         # launch period of a stream = kernel duration (rocprofv3 --kernel-trace: profiles/) + dispatch gap
                          "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

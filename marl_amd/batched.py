@@ -134,9 +134,10 @@ class BatchedAssemblyEnv:
         step's prior then redoes its own nearest-cell search (AssemblyEnv.cpp:1107)."""
         self._recompute_target = True
 
-    def step(self, a: torch.Tensor):
+    def step(self, a: torch.Tensor, stream_ptr: Optional[int] = None):
         """assembly.py:482-661 ('input' strategy).  a: (E, 2, n_a) float32 on the device.
-        Returns (obs, reward, done, info, a_prior) like the reference's 5-tuple."""
+        Returns (obs, reward, done, info, a_prior) like the reference's 5-tuple.
+        stream_ptr: the HIP stream to launch on (default: torch's current stream on this device)."""
         if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.p.device or \
                 tuple(a.shape) != (self.E, 2, self.n_a):
             raise ValueError(f"actions must be a contiguous float32 tensor of shape {(self.E, 2, self.n_a)} on {self.device}")
@@ -152,7 +153,8 @@ class BatchedAssemblyEnv:
                                _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior),
                                _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.stats), 0, None]
         args = self._step_args
-        args[4] = C.c_void_p(a.data_ptr()); args[17] = int(self._recompute_target); args[18] = self._stream()
+        args[4] = C.c_void_p(a.data_ptr()); args[17] = int(self._recompute_target)
+        args[18] = self._stream() if stream_ptr is None else C.c_void_p(stream_ptr)
         if torch.cuda.current_device() == self._dev_index:
             rc = self.lib.asm_batch_step_f32(*args)
         else:

@@ -65,6 +65,7 @@ class StreamShards:
         self.device = torch.device(device)
         self.parts, self.E, self.n_a = parts, int(num_envs), int(n_a)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self._stream_ptrs = [s.cuda_stream for s in self.streams]
         self.envs = []
         first = 0
         for k in range(parts):
@@ -86,8 +87,9 @@ class StreamShards:
         return self.on_each(lambda k, env: env.reset(episode))
 
     def step(self, actions):
-        """actions: one (E_k, 2, n_a) tensor per shard, produced on that shard's stream."""
-        return self.on_each(lambda k, env: env.step(actions[k]))
+        """actions: one (E_k, 2, n_a) tensor per shard, produced on that shard's stream.  The launches name
+        their stream explicitly, so no stream context is entered on the host."""
+        return [env.step(actions[k], self._stream_ptrs[k]) for k, env in enumerate(self.envs)]
 
     def synchronize(self) -> None:
         for s in self.streams:
