@@ -261,7 +261,7 @@ __device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, 
     const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
     const f32x2 thr = {P.Tsen_f, P.Thalf_f};
     for (int w = 0; w < P.W; ++w) {
-        unsigned k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, word = 0, ocand = 0;
+        unsigned k1 = 0xFFFFFFFFu, word = 0, ocand = 0;              // k1: the word's smallest s32 (bit pattern)
         float amb = __builtin_inff(), ambo = __builtin_inff();
         const float4 *X = reinterpret_cast<const float4 *>(gx + w * 32);
         const float4 *Y = reinterpret_cast<const float4 *>(gy + w * 32);
@@ -273,12 +273,11 @@ __device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, 
             const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
             const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
             const float ss[4] = {sa.x, sa.y, sb.x, sb.y};
+            k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
+            k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sv = ss[r];
-                const unsigned key = (__float_as_uint(sv) & ~31u) | (unsigned)(q * 4 + r);
-                k2 = umed3(k1, k2, key);
-                k1 = k1 < key ? k1 : key;
                 const f32x2 s2 = {sv, sv};
                 const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half)
                 word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
@@ -291,38 +290,59 @@ __device__ __forceinline__ int cell_pass_words(const DevParams &P, bool active, 
         wkey[w] = (unsigned short)(k1 >> 16);
         if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
         settle_occupancy(P, active, __brev(ocand), ambo, px, py, gx + w * 32, gy + w * 32, &occ[w], &cov[w]);
-        if (k1 < G1) G1w = (unsigned)w;
-        const unsigned t = G1 > k1 ? G1 : k1, m = G2 < k2 ? G2 : k2;
-        G2 = m < t ? m : t;
+        if (k1 < G1) G1w = (unsigned)w;                                     // strict: the first word holding the smallest s32
+        G2 = umed3(G1, G2, k1);                                             // the two smallest word minima
         G1 = G1 < k1 ? G1 : k1;
     }
-    int imin = (int)(G1w * 32 + (G1 & 31u));
-    const bool amb_min = !((G2 >> 5) - (G1 >> 5) >= 2u);
-    if (amb_min)                                                            // words holding a candidate for the minimum
-        for (int w = 0; w < P.W; ++w) if ((unsigned)wkey[w] - (G1 >> 16) < 2u) ambw |= 1u << w;
-    if (ambw) {
-        double best = __builtin_inf(); int besti = imin;
-        const unsigned lo = G1 >> 5;
-        while (ambw) {
-            const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
-            unsigned word = mw[w];
-#pragma unroll 4
-            for (int b = 0; b < 32; ++b) {
-                const int c = w * 32 + b;
-                const float rx = gx[c] - pxf, ry = gy[c] - pyf;
-                const float s32 = __builtin_fmaf(ry, ry, rx * rx);
-                const bool a = __builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f;
-                const bool m = amb_min && ((__float_as_uint(s32) >> 5) - lo < 2u);
-                if (a || m) {
-                    const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
-                    const double sd = dx * dx + dy * dy;
-                    if (a) { if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b); }
-                    if (m && sd < best) { best = sd; besti = c; }           // ascending index + strict '<': first minimum
-                }
-            }
-            mw[w] = word;
+    // Nearest cell: the candidates are the cells whose s32 lies within two units of 32 ulps of the smallest one; they
+    // sit in its word and, rarely, in words whose minimum is that close (16-bit keys: a coarser, safe test).  Those
+    // words are screened again (same arithmetic, same s32) and the candidates compared in double, ascending index +
+    // strict '<': the reference's first minimum (CPP:889).
+    const unsigned lo = G1 >> 5, lim = (lo << 5) + 64u;
+    unsigned minw = active ? 1u << G1w : 0u;                                // padding lanes have no nearest cell
+    if (active && !((G2 >> 5) - lo >= 2u))
+        for (int w = 0; w < P.W; ++w) if ((unsigned)wkey[w] - (G1 >> 16) < 2u) minw |= 1u << w;
+    double best = __builtin_inf(); int imin = 0;
+    while (minw) {
+        const int w = __ffs(minw) - 1; minw &= minw - 1;
+        const float4 *X = reinterpret_cast<const float4 *>(gx + w * 32);
+        const float4 *Y = reinterpret_cast<const float4 *>(gy + w * 32);
+        unsigned cand = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 x4 = X[q], y4 = Y[q];
+            const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+            const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+            const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+            const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.x) - lim, 31);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.y) - lim, 31);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.x) - lim, 31);
+            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.y) - lim, 31);
         }
-        if (amb_min) imin = besti;
+        cand = __brev(cand);
+        while (cand) {
+            const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
+            const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
+            const double sd = dx * dx + dy * dy;
+            if (sd < best) { best = sd; imin = c; }
+        }
+    }
+    while (ambw) {                                                          // rare: sensed bits within the margin of T_sen
+        const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
+        unsigned word = mw[w];
+#pragma unroll 4
+        for (int b = 0; b < 32; ++b) {
+            const int c = w * 32 + b;
+            const float rx = gx[c] - pxf, ry = gy[c] - pyf;
+            const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+            if (__builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f) {
+                const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
+                const double sd = dx * dx + dy * dy;
+                if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b);
+            }
+        }
+        mw[w] = word;
     }
     return imin;
 }
