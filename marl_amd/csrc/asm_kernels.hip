@@ -1195,16 +1195,49 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 n2 = umed3(n1, n2, key); n1 = n1 < key ? n1 : key;                        // and the nearest neighbour
             }
         }
-        cand = __brev(cand) & ~(1u << i);
-        while (cand) {                                              // ascending j: ties keep the lower index
-            const int j = __ffs(cand) - 1; cand &= cand - 1;
-            const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
-            const double s = dx * dx + dy * dy;                     // CPP:641
-            if (s < P.T_sen) {                                      // CPP:663; self removed CPP:677-681
-                double ks = s; int kj = j; bool placed = false;     // once placed, the entries behind move down one place
+        cand = __brev(cand) & ~(1u << i);                           // self removed CPP:677-681
+        // The candidates' single-precision keys (s32 with the low 5 bits replaced by the index) go through a
+        // min/max insertion chain that keeps the 7 smallest in order.  The order of the first six -- among
+        // themselves and against the seventh, hence against everything else -- is certain when neighbouring keys
+        // differ by at least two units of 32 ulps (the screen is off by a few ulps), and a listed agent is
+        // certainly inside d_sen when its key lies two units below T_sen.  Otherwise (ties, near-ties, agents at
+        // the sensing range) the lane redoes its list in double below.
+        const unsigned cand_all = cand;
+        unsigned K[7];
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
-                    if (placed || ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
+        for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
+        while (cand) {
+            const int j = __builtin_ctz(cand); cand &= cand - 1;
+            const float rx = L.px[es * 32 + j] - pxf, ry = L.py[es * 32 + j] - pyf;
+            unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~31u) | (unsigned)j;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+        }
+        const unsigned tlo = (__float_as_uint(P.Tsen_f) >> 5) - 2u;
+        bool redo = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const bool there = K[q] != 0xFFFFFFFFu;
+            const unsigned u = K[q] >> 5;
+            redo |= there && (u >= tlo || (K[q + 1] >> 5) - u < 2u);
+            j6[q] = there ? (int)(K[q] & 31u) : -1;
+        }
+        if (__ballot(redo)) {                                       // rare
+            if (redo) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) j6[q] = -1;
+                cand = cand_all;
+                while (cand) {                                      // ascending j: ties keep the lower index
+                    const int j = __ffs(cand) - 1; cand &= cand - 1;
+                    const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+                    const double s = dx * dx + dy * dy;             // CPP:641
+                    if (s < P.T_sen) {                              // CPP:663
+                        double ks = s; int kj = j; bool placed = false;     // once placed, the entries behind move down one place
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            if (placed || ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
+                    }
+                }
             }
         }
         if (P.want_stats && n_a > 1) {
