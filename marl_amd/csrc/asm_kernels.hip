@@ -466,18 +466,51 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if (swarm) {
             if constexpr (F32) {
                 const float pxf = L.px[i], pyf = L.py[i];
+                // Candidates (fp32 screen) go through a min/max insertion chain on single-precision keys (s32 with
+                // the low 10 bits replaced by the index) that keeps the 7 smallest.  The list is read off the keys
+                // when every neighbouring pair differs by at least two units of 1024 ulps and every listed key lies
+                // two units below T_sen; otherwise this agent redoes its list with exact double insertion.
+                unsigned K[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
                 for (int j0 = 0; j0 < P.SL; j0 += 32) {
                     unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
                     if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));        // self removed CPP:677-681
-                    while (m) {                                                 // ascending j: ties keep the lower index
-                        const int j = j0 + __ffs(m) - 1; m &= m - 1;
-                        const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
-                        const double s = dx * dx + dy * dy;                     // CPP:641
-                        if (s < P.T_sen) consider(j, s);                        // CPP:663
+                    while (m) {
+                        const int j = j0 + __builtin_ctz(m); m &= m - 1;
+                        const float rx = L.px[j] - pxf, ry = L.py[j] - pyf;
+                        unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~1023u) | (unsigned)j;
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                    }
+                }
+                const unsigned tlo = (__float_as_uint(P.Tsen_f) >> 10) - 2u;
+                bool redo = false;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const bool there = K[q] != 0xFFFFFFFFu;
+                    const unsigned u = K[q] >> 10;
+                    redo |= there && (u >= tlo || (K[q + 1] >> 10) - u < 2u);
+                    j6[q] = there ? (int)(K[q] & 1023u) : -1;
+                }
+                if (redo) {                                                     // rare
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) j6[q] = -1;
+                    for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                        unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
+                        if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
+                        while (m) {                                             // ascending j: ties keep the lower index
+                            const int j = j0 + __ffs(m) - 1; m &= m - 1;
+                            const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                            const double s = dx * dx + dy * dy;                 // CPP:641
+                            if (s < P.T_sen) consider(j, s);                    // CPP:663
+                        }
                     }
                 }
                 if (P.want_stats) {                                             // nearest other agent (WRAP:81-99)
-                    if (s6[0] > 0.0 && j6[0] >= 0) nn_min = s6[0];
+                    double s0 = 0.0;
+                    if (j6[0] >= 0) { const double dx = (double)L.px[j6[0]] - px, dy = (double)L.py[j6[0]] - py; s0 = dx * dx + dy * dy; }
+                    if (s0 > 0.0) nn_min = s0;
                     else
                         for (int j = 0; j < n_a; ++j) {
                             const double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py, su = rx * rx + ry * ry;
