@@ -28,6 +28,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 EPISODE_LENGTH = 200           # marl_llm/cfg/assembly_cfg.py:192
+SETTLE_STEPS = 400             # untimed steps of continuous load before the step time is steady
 
 
 def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
@@ -211,6 +212,12 @@ def main():
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
     barrier()
     mark("environment reset, actions drawn")
+    # The step time settles only after about 400 steps (25 ms) of continuous load (clock ramp): when fewer warm-up
+    # steps are asked for, the difference is stepped first and the environments are put back to their episode-0 state.
+    if W < SETTLE_STEPS:
+        for t in range(SETTLE_STEPS - W):
+            shards.step([a[t % ring] for a in actions])
+        shards.on_each(lambda k, env: reset_one(k, env, 0))
     run_steps(W)
     mark("warm-up steps done")
     shards.on_each(lambda k, env: totals[k].add_(reduce_episode_stats(env.episode_stats())))
