@@ -490,3 +490,32 @@ def test_lattice_states_full_of_ties(torch_cuda, monkeypatch, n_a, step_denomina
     for t in range(3):
         act = rng.integers(-4, 5, (E, 2, n_a)).astype(np.float32) * 0.25
         teacher_forced_step(env, cfg, act, f"lattice step {t}")
+
+
+@pytest.mark.parametrize("n_g_max", [None, 1056])
+def test_extreme_grid_sizes(torch_cuda, n_g_max):
+    """Shapes of 1024 cells (32 mask words, the largest the multi-wave kernel takes), 33 cells, 5 cells and a
+    single cell in one batch; with n_g_max = 1056 the same batch goes through the generic kernel."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    l = 0.05
+    yy, xx = np.mgrid[0:32, 0:32]
+    big = np.stack([(xx.ravel() - 15.5) * l, (yy.ravel() - 15.5) * l], axis=1)          # 1024 cells
+    shapes = ([l, l, l, l], [big, big[:33] + [0.0, 0.8], big[:5] + [0.4, 0.8], big[:1] + [0.8, 0.8]])
+    E, n_a = 9, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=77, shapes=shapes, r_avoid=0.26, keep_indices=True, n_g_max=n_g_max)
+    assert env.n_g_max == (1024 if n_g_max is None else 1056)
+    cfg = cfg_from_env(env)
+    env.reset()
+    assert set(env.n_g.cpu().tolist()) <= {1024, 33, 5, 1}
+    check_observation(env, cfg, False, "reset")
+    rng = np.random.default_rng(1)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy(); p = env.p.cpu().numpy()
+    for e in range(0, E, 2):                                    # half of the environments: agents onto their shape
+        p[e] = grid[e][:, rng.integers(0, n_g[e], n_a)] + rng.normal(0, 0.05, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.observe(want_reward=True)
+    check_observation(env, cfg, True, "packed observe")
+    for t in range(3):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"step {t}")
+    assert (env.sensed_index >= 0).sum(dim=2).max().item() == 80     # the big shape fills (and sub-samples) the list
