@@ -35,7 +35,8 @@ class BatchedAssemblyEnv:
     def __init__(self, num_envs: int, n_a: int = 30, *, device="cuda", seed: int = 226, env_id_offset: int = 0,
                  is_boundary: bool = True, is_con_self_state: bool = True, training_method: str = "llm_rl",
                  shapes=None, r_avoid: Optional[float] = None, d_sen: float = 0.4, n_g_max: Optional[int] = None,
-                 keep_indices: bool = False, keep_stats: bool = True):
+                 keep_indices: bool = False, keep_stats: bool = True, num_obs_grid_max: int = 80,
+                 num_occupied_grid_max: int = 200):
         self.lib = _lib.load()
         self.E = int(num_envs)
         self.n_a = int(n_a)
@@ -56,7 +57,9 @@ class BatchedAssemblyEnv:
         self.training_method = training_method
         self.params = _lib.default_params(self.n_a, self.n_g_max, self.r_avoid, is_boundary=int(is_boundary),
                                           is_con_self_state=int(is_con_self_state), d_sen=d_sen,
-                                          compute_prior=int(training_method == "llm_rl"))
+                                          compute_prior=int(training_method == "llm_rl"),
+                                          num_obs_grid_max=int(num_obs_grid_max),            # assembly.py:126
+                                          num_occupied_grid_max=int(num_occupied_grid_max))  # assembly.py:128
         self.obs_dim_agent = self.lib.asm_obs_dim(C.byref(self.params))
         # spaces as the learner reads them (assembly.py:806-812; maddpg.py:264-266 reads .shape)
         self.observation_space = SimpleNamespace(shape=(self.obs_dim_agent, self.n_a), dtype=np.float32)
@@ -81,8 +84,8 @@ class BatchedAssemblyEnv:
         self.reward = torch.zeros(E, 1, n, **f32)
         self.a_prior = torch.zeros(E, 2, n, **f32)
         self.done = torch.zeros(E, 1, n, dtype=torch.bool, device=dev)          # assembly.py:475-477
-        self.sensed_index = torch.full((E, n, 80), -1, **i32) if keep_indices else None
-        self.occupied_index = torch.full((E, n, 200), -1, **i32) if keep_indices else None
+        self.sensed_index = torch.full((E, n, int(num_obs_grid_max)), -1, **i32) if keep_indices else None
+        self.occupied_index = torch.full((E, n, int(num_occupied_grid_max)), -1, **i32) if keep_indices else None
         self.stats = torch.zeros(E, 8, dtype=torch.float64, device=dev) if keep_stats else None
         # canonical shapes on the device (results.pkl 'grid_coords' layout, assembly.py:115)
         off = np.zeros(self.num_train_shape, np.int32)

@@ -28,7 +28,8 @@ def assert_close(got_f32, want_f64, what, max_ulp=1):
 def cfg_from_env(env):
     return ol.make_cfg(n_a=env.n_a, r_avoid=env.r_avoid, is_boundary=bool(env.params.is_boundary),
                        is_con_self_state=bool(env.params.is_con_self_state), d_sen=env.params.d_sen,
-                       llm_rl=env.training_method == "llm_rl")
+                       llm_rl=env.training_method == "llm_rl", num_obs_grid_max=env.params.num_obs_grid_max,
+                       num_occupied_grid_max=env.params.num_occupied_grid_max)
 
 
 def oracle_observe_batch(cfg, p, dp, grid, n_g, l_cell):

@@ -519,3 +519,28 @@ def test_extreme_grid_sizes(torch_cuda, n_g_max):
     for t in range(3):
         teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"step {t}")
     assert (env.sensed_index >= 0).sum(dim=2).max().item() == 80     # the big shape fills (and sub-samples) the list
+
+
+@pytest.mark.parametrize("cap,occ_cap,fast_t", [(80, 200, "4"), (30, 40, "4"), (100, 64, "4"), (6, 8, "4"), (30, 40, "2"),
+                                                (100, 64, "1"), (31, 40, "4"), (30, 40, "0")])
+def test_other_list_capacities(torch_cuda, monkeypatch, cap, occ_cap, fast_t):
+    """num_obs_grid_max / num_occupied_grid_max other than the reference's 80 / 200 (assembly.py:126-128): slot
+    ranges per wave, sub-sampling and the observation layout all follow the capacity.  An odd capacity is served
+    by the generic kernel."""
+    torch = torch_cuda
+    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E, n_a = 10, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=cap, keep_indices=True, num_obs_grid_max=cap, num_occupied_grid_max=occ_cap)
+    assert env.obs.shape[1] == 32 + 2 * cap
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(cap)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy(); p = env.p.cpu().numpy()
+    for e in range(0, E, 2):
+        p[e] = grid[e][:, rng.choice(n_g[e], n_a, replace=False)] + rng.normal(0, 0.03, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.observe(want_reward=True)
+    check_observation(env, cfg, True, "observe")
+    for t in range(3):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"cap {cap} step {t}")
