@@ -544,3 +544,52 @@ def test_other_list_capacities(torch_cuda, monkeypatch, cap, occ_cap, fast_t):
     check_observation(env, cfg, True, "observe")
     for t in range(3):
         teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"cap {cap} step {t}")
+
+
+@pytest.mark.parametrize("fast_t", ["4", "0"])
+def test_non_default_physics(torch_cuda, monkeypatch, fast_t):
+    """Every scalar of asm_params away from the reference's default (mass != 1 takes the division of
+    assembly.py:638): dynamics, prior and observation against the oracle configured alike."""
+    torch = torch_cuda
+    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E, n_a = 8, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=3, keep_indices=True, r_avoid=0.31, d_sen=0.55)
+    over = dict(size_a=0.05, vel_max=0.5, k_ball=22.0, k_wall=70.0, c_wall=3.5, dt=0.07, sensitivity=0.6, mass=2.5,
+                half_w=2.0, half_h=2.2)
+    for k, v in over.items():
+        setattr(env.params, k, v)
+    cfg = cfg_from_env(env)
+    for k, v in over.items():
+        setattr(cfg, "Vel_max" if k == "vel_max" else k, v)
+    env.reset()
+    rng = np.random.default_rng(0)
+    p = env.p.cpu().numpy()
+    p[:, 0] = np.clip(p[:, 0], -2.05, 2.05); p[:, 1] = np.clip(p[:, 1], -2.25, 2.25)     # some agents into the (moved) walls
+    for e in range(0, E, 2):
+        grid = env.grid_center[e].cpu().numpy(); n_g = int(env.n_g[e])
+        p[e] = grid[:, rng.choice(n_g, n_a, replace=False)] + rng.normal(0, 0.03, (2, n_a))
+    env.p.copy_(torch.from_numpy(p.astype(np.float32))); env.observe(want_reward=True)
+    check_observation(env, cfg, True, "observe")
+    for t in range(4):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"physics step {t}")
+
+
+def test_without_prior_and_without_self_state(torch_cuda):
+    """training_method other than 'llm_rl' (no prior, assembly.py:600) and is_con_self_state = False (the
+    observation drops the agent's own four rows, assembly.py:105, 806)."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env, check_observation, teacher_forced_step
+    E, n_a = 7, 30
+    env = BatchedAssemblyEnv(E, n_a, seed=13, keep_indices=True, training_method="rl", is_con_self_state=False)
+    assert env.obs.shape[1] == 188
+    cfg = cfg_from_env(env)
+    env.reset()
+    check_observation(env, cfg, False, "reset")
+    rng = np.random.default_rng(6)
+    for t in range(3):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        teacher_forced_step(env, cfg, act, f"step {t}")
+    assert env.step(torch.zeros(E, 2, n_a, device="cuda"))[4] is None
