@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             }
             dmin = sqrt(smin);
             const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;     // CPP:894
-            L.fin[l] = (unsigned)imin | (in_flag ? 0x80000000u : 0u);
+            L.fin[l] = (unsigned)imin | ((unsigned)contacts << 16) | (in_flag ? 0x80000000u : 0u);   // imin < 1024, contacts < 32
             inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;        // CPP:139
             nearest_g[(size_t)e * n_a + i] = imin;
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
@@ -1434,6 +1434,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         } else {
             L.fin[l] = 0;
         }
+        if (T > 1 && P.want_stats)                                  // wave 1 computes the formation statistics in P7
+            L.part[l] = make_uint4(__double2loint(dmin), __double2hiint(dmin), __double2loint(nn_min), __double2hiint(nn_min));
     }
     STAMP(13);
     __syncthreads();
@@ -1691,25 +1693,39 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             if (P.want_reward) rew_g[(size_t)e * n_a + i] = (float)reward;
         }
         STAMP(8);
-        if (P.want_stats) {                                         // TRAIN:128-135; WRAP:48-165
-            const double m = active ? sqrt(nn_min) : 0.0;
+        if (P.want_stats) {                                         // TRAIN:128-131: reward sums, agents inside
             const unsigned long long half = es ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
             const double rs = (double)__popcll(__ballot(active && reward > 0.0) & half), rq = rs;     // rewards are 0 or 1
             const double inn = (double)__popcll(__ballot(active && in_flag) & half);
-            int ci = contacts + (i < W ? __popc(cov_e[i]) << 16 : 0);                                 // two small sums in one word
-#pragma unroll
-            for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
-            const double cp = (double)(ci & 0xFFFF), covered = (double)(ci >> 16);
-            const double ds = half_sum(active ? dmin : 0.0), ms = half_sum(m);
-            const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
-            const double mean = ms / n_a, dv = active ? m - mean : 0.0;
-            const double var = half_sum(dv * dv) / n_a;
             if (i == 0 && env_ok) {
                 double *st = stats_g + (size_t)e * 8;
-                st[0] += rs; st[1] += rq; st[2] += covered / n_g;
-                st[3] += (var - lo) / (hi - lo);                    // WRAP:98-99
-                st[4] += cp; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+                st[0] += rs; st[1] += rq; st[7] += inn;
             }
+        }
+    }
+    // Formation statistics (TRAIN:132-135; WRAP:48-165): they do not depend on the reward, so with several waves the
+    // second one computes them while the first evaluates the reward (its inputs were handed over through LDS in P4).
+    if (sub == SUB_PRIOR && P.want_stats) {
+        double dm = dmin, nn = nn_min; int cn = contacts;
+        if (T > 1) {
+            const uint4 q = L.part[l];
+            dm = __hiloint2double((int)q.y, (int)q.x); nn = __hiloint2double((int)q.w, (int)q.z);
+            cn = (int)((fin >> 16) & 0xFFu);
+        }
+        const double m = active ? sqrt(nn) : 0.0;
+        int ci = cn + (i < W ? __popc(cov_e[i]) << 16 : 0);                                           // two small sums in one word
+#pragma unroll
+        for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
+        const double cp = (double)(ci & 0xFFFF), covered = (double)(ci >> 16);
+        const double ds = half_sum(active ? dm : 0.0), ms = half_sum(m);
+        const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
+        const double mean = ms / n_a, dv = active ? m - mean : 0.0;
+        const double var = half_sum(dv * dv) / n_a;
+        if (i == 0 && env_ok) {
+            double *st = stats_g + (size_t)e * 8;
+            st[2] += covered / n_g;
+            st[3] += (var - lo) / (hi - lo);                        // WRAP:98-99
+            st[4] += cp; st[5] += ds / n_a; st[6] += 1.0;
         }
     }
     STAMP(9);
