@@ -1494,9 +1494,15 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             busy = busy && bits != 0;
             unsigned short *wp = mysel + rank, *const wend = mysel + k1;
             unsigned wbase = (wq & 31u) << 5;
-            while (busy) {                                          // bits != 0 here
+            while (busy) {                                          // bits != 0 here; two cells of the word per trip
                 const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
-                *wp++ = (unsigned short)(wbase | b);
+                *wp = (unsigned short)(wbase | b);
+                // the word's next cell, if it has one, goes to the next slot in the same trip (no branch: without
+                // one the first cell is stored once more in place)
+                const bool two = bits != 0;
+                const unsigned b2 = (unsigned)(__ffs(bits) - 1); bits &= bits - 1;      // bits == 0 stays 0
+                wp[two ? 1 : 0] = (unsigned short)(wbase | (two ? b2 : b));
+                wp += two ? 2 : 1;
                 ++diag_it;
                 if (bits == 0) {
 #pragma unroll
