@@ -151,20 +151,34 @@ size_t g_ws_bytes = 0;
 }
 #define HIP_OR_DIE(call) do { hipError_t _e = (call); if (_e != hipSuccess) die(#call, _e); } while (0)
 
+// One call = inputs gathered into a pinned host buffer, ONE host-to-device copy, the kernel, ONE device-to-host copy
+// of the outputs, one stream synchronisation: the device workspace and the pinned buffer share a layout
+// (inputs first, outputs behind them).
 struct Arena {
     size_t off = 0;
     template <typename T> size_t take(size_t n) { size_t o = off; off += (n * sizeof(T) + 255) / 256 * 256; return o; }
 };
+unsigned char *g_host = nullptr;                             // pinned mirror of g_ws
+hipStream_t g_stream = nullptr;
 void ensure_ws(size_t bytes)
 {
+    if (!g_stream) HIP_OR_DIE(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     if (bytes <= g_ws_bytes) return;
-    if (g_ws) HIP_OR_DIE(hipFree(g_ws));
+    if (g_ws) { HIP_OR_DIE(hipFree(g_ws)); HIP_OR_DIE(hipHostFree(g_host)); }
+    bytes = bytes * 2 + 4096;                                // head-room: the sizes of a run rarely change
     HIP_OR_DIE(hipMalloc((void **)&g_ws, bytes));
+    HIP_OR_DIE(hipHostMalloc((void **)&g_host, bytes, hipHostMallocDefault));
     g_ws_bytes = bytes;
 }
 template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(g_ws + off); }
-template <typename T> void h2d(size_t off, const T *src, size_t n) { HIP_OR_DIE(hipMemcpy(g_ws + off, src, n * sizeof(T), hipMemcpyHostToDevice)); }
-template <typename T> void d2h(T *dst, size_t off, size_t n) { HIP_OR_DIE(hipMemcpy(dst, g_ws + off, n * sizeof(T), hipMemcpyDeviceToHost)); }
+template <typename T> void put(size_t off, const T *src, size_t n) { std::memcpy(g_host + off, src, n * sizeof(T)); }
+template <typename T> void get(T *dst, size_t off, size_t n) { std::memcpy(dst, g_host + off, n * sizeof(T)); }
+void upload(size_t end) { HIP_OR_DIE(hipMemcpyAsync(g_ws, g_host, end, hipMemcpyHostToDevice, g_stream)); }
+void download(size_t begin, size_t end)
+{
+    HIP_OR_DIE(hipMemcpyAsync(g_host + begin, g_ws + begin, end - begin, hipMemcpyDeviceToHost, g_stream));
+    HIP_OR_DIE(hipStreamSynchronize(g_stream));
+}
 
 void compat_params(asm_params *a, int n_a, int n_g, int topo, int n_obs, int n_occ, double d_sen, double r_avoid,
                    const double *bpos)
@@ -360,17 +374,18 @@ void _get_observation(double *p_in, double *dp_in, double *heading_in, double *o
     size_t o_obs = A.take<double>((size_t)obs_dim_agent * na), o_nbr = A.take<int>(na * 6), o_in = A.take<int>(na);
     size_t o_near = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_occ = A.take<int>(na * P.n_occ);
     ensure_ws(A.off);
-    h2d(o_p, p_in, 2 * na); h2d(o_dp, dp_in, 2 * na); h2d(o_h, heading_in, 2 * na); h2d(o_g, grid_in, 2 * ng);
-    h2d(o_ng, &n_g, 1); h2d(o_lc, &l_cell, 1);
-    HIP_OR_DIE(hipMemset(g_ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double)));   // CPP:49 zero-initialised
+    put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_h, heading_in, 2 * na); put(o_g, grid_in, 2 * ng);
+    put(o_ng, &n_g, 1); put(o_lc, &l_cell, 1);
+    upload(o_obs);                                           // the inputs end where the outputs begin
+    HIP_OR_DIE(hipMemsetAsync(g_ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double), g_stream));   // CPP:49 zero-initialised
     int rc = asmenv::launch_observe<double>(P, at<double>(o_p), at<double>(o_dp), at<double>(o_h), at<double>(o_g),
                                             at<int>(o_ng), at<double>(o_lc), at<int>(o_nbr), at<int>(o_in),
                                             at<int>(o_near), at<double>(o_obs), nullptr, at<int>(o_sen),
-                                            at<int>(o_occ), nullptr);
+                                            at<int>(o_occ), g_stream);
     if (rc) die("_get_observation kernel launch", (hipError_t)rc);
-    HIP_OR_DIE(hipDeviceSynchronize());
-    d2h(obs_io, o_obs, (size_t)obs_dim_agent * na); d2h(nbr_io, o_nbr, na * 6); d2h(inflags_io, o_in, na);
-    d2h(sensed_io, o_sen, na * P.n_obs); d2h(occupied_io, o_occ, na * P.n_occ);
+    download(o_obs, A.off);
+    get(obs_io, o_obs, (size_t)obs_dim_agent * na); get(nbr_io, o_nbr, na * 6); get(inflags_io, o_in, na);
+    get(sensed_io, o_sen, na * P.n_obs); get(occupied_io, o_occ, na * P.n_occ);
 }
 
 void _get_reward(double *p_in, double *dp_in, double *heading_in, double *act_in, double *reward_io, double *bpos,
@@ -394,14 +409,15 @@ void _get_reward(double *p_in, double *dp_in, double *heading_in, double *act_in
     size_t o_p = A.take<double>(2 * na), o_g = A.take<double>(2 * ng), o_nbr = A.take<int>(na * topo_nei_max);
     size_t o_in = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_r = A.take<double>(na);
     ensure_ws(A.off);
-    h2d(o_p, p_in, 2 * na); h2d(o_g, grid_in, 2 * ng); h2d(o_nbr, nbr_in, na * topo_nei_max);
-    h2d(o_in, inflags_in, na); h2d(o_sen, sensed_in, na * P.n_obs);
+    put(o_p, p_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
+    put(o_in, inflags_in, na); put(o_sen, sensed_in, na * P.n_obs);
+    upload(o_r);
     int rc = asmenv::launch_reward_compat(P, at<double>(o_p), at<double>(o_g), n_g, at<int>(o_nbr), at<int>(o_in),
                                           at<int>(o_sen), condition[0], condition[3], condition[4], at<double>(o_r),
-                                          nullptr);
+                                          g_stream);
     if (rc) die("_get_reward kernel launch", (hipError_t)rc);
-    HIP_OR_DIE(hipDeviceSynchronize());
-    d2h(reward_io, o_r, na);
+    download(o_r, A.off);
+    get(reward_io, o_r, na);
 }
 
 void _sf_b2b_all(double *p_in, double *sf_io, double *d_edge_in, bool *collide_in, double *bpos, double *d_center_in,
@@ -415,13 +431,14 @@ void _sf_b2b_all(double *p_in, double *sf_io, double *d_edge_in, bool *collide_i
     size_t o_p = A.take<double>(2 * na), o_de = A.take<double>(na * na), o_dc = A.take<double>(na * na);
     size_t o_c = A.take<bool>(na * na), o_sf = A.take<double>(2 * na);
     ensure_ws(A.off);
-    h2d(o_p, p_in, 2 * na); h2d(o_de, d_edge_in, na * na); h2d(o_dc, d_center_in, na * na); h2d(o_c, collide_in, na * na);
+    put(o_p, p_in, 2 * na); put(o_de, d_edge_in, na * na); put(o_dc, d_center_in, na * na); put(o_c, collide_in, na * na);
+    upload(o_sf);
     const double hw = (bpos[2] - bpos[0]) / 2.0, hh = (bpos[1] - bpos[3]) / 2.0;                   // CPP:776-777
     int rc = asmenv::launch_sf_b2b_compat(at<double>(o_p), at<double>(o_de), at<bool>(o_c), at<double>(o_dc), n_a,
-                                          k_ball, is_periodic, hw, hh, at<double>(o_sf), nullptr);
+                                          k_ball, is_periodic, hw, hh, at<double>(o_sf), g_stream);
     if (rc) die("_sf_b2b_all kernel launch", (hipError_t)rc);
-    HIP_OR_DIE(hipDeviceSynchronize());
-    d2h(sf_io, o_sf, 2 * na);
+    download(o_sf, A.off);
+    get(sf_io, o_sf, 2 * na);
 }
 
 void _get_dist_b2w(double *p_in, double *r_in, double *d_b2w_io, bool *coll_io, int dim, int n_a, double *bpos)
@@ -433,12 +450,13 @@ void _get_dist_b2w(double *p_in, double *r_in, double *d_b2w_io, bool *coll_io, 
     Arena A;
     size_t o_p = A.take<double>(2 * na), o_r = A.take<double>(na), o_d = A.take<double>(4 * na), o_c = A.take<bool>(4 * na);
     ensure_ws(A.off);
-    h2d(o_p, p_in, 2 * na); h2d(o_r, r_in, na);
+    put(o_p, p_in, 2 * na); put(o_r, r_in, na);
+    upload(o_d);
     int rc = asmenv::launch_dist_b2w_compat(at<double>(o_p), at<double>(o_r), n_a, bpos, at<double>(o_d), at<bool>(o_c),
-                                            nullptr);
+                                            g_stream);
     if (rc) die("_get_dist_b2w kernel launch", (hipError_t)rc);
-    HIP_OR_DIE(hipDeviceSynchronize());
-    d2h(d_b2w_io, o_d, 4 * na); d2h(coll_io, o_c, 4 * na);
+    download(o_d, A.off);
+    get(d_b2w_io, o_d, 4 * na); get(coll_io, o_c, 4 * na);
 }
 
 void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, double *grid_in, int *nbr_in, double d_sen,
@@ -456,12 +474,13 @@ void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, doubl
     size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_g = A.take<double>(2 * ng);
     size_t o_nbr = A.take<int>(na * topo_nei_max), o_a = A.take<double>(2 * na);
     ensure_ws(A.off);
-    h2d(o_p, p_in, 2 * na); h2d(o_dp, dp_in, 2 * na); h2d(o_g, grid_in, 2 * ng); h2d(o_nbr, nbr_in, na * topo_nei_max);
+    put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
+    upload(o_a);
     int rc = asmenv::launch_prior_compat(P, at<double>(o_p), at<double>(o_dp), at<double>(o_g), n_g, at<int>(o_nbr),
-                                         l_cell, at<double>(o_a), nullptr);
+                                         l_cell, at<double>(o_a), g_stream);
     if (rc) die("calculateActionPrior kernel launch", (hipError_t)rc);
-    HIP_OR_DIE(hipDeviceSynchronize());
-    d2h(a_prior_io, o_a, 2 * na);
+    download(o_a, A.off);
+    get(a_prior_io, o_a, 2 * na);
 }
 
 }  // extern "C"
