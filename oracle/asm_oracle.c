@@ -658,7 +658,7 @@ static double draw_uniform(uint64_t seed, uint64_t env, uint32_t ep, uint32_t d,
     return lo + (hi - lo) * u;
 }
 
-/* ENV:151-218 with the draw order of §reset: shape, angle, 2 discarded, offset x/y, coin,
+/* ENV:151-218 with the draw order of the reference reset: shape, angle, 2 discarded, offset x/y, coin,
  * 2*n_a position draws, 2 centre draws, 2*n_a velocity draws. */
 void oracle_batch_reset(uint64_t seed, uint32_t episode, int64_t env0, int E, int n_a, int n_shapes,
                         const double *shape_grids, const int *shape_off, const int *shape_ng,
