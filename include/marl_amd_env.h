@@ -182,6 +182,17 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
                                  float *act, void *stream);
 
 /*
+ * The in-environment 'rule' expert (assembly.py:525-596; what eval/collect_expert_data.py drives): actions
+ * [E][2][n_a] for the state the last observation call saw, from that call's in_flags, nearest_cell and
+ * sensed_index (required here: the lists of assembly.py:539-567 are exactly the observation's sensed lists).
+ * Evaluated in double in the reference's order, clipped to [-1, 1] and rounded to float (the reference
+ * feeds its dynamics the double values: the difference is one float32 rounding of the action).
+ */
+int asm_batch_rule_actions_f32(const asm_params *prm, int E, const float *p, const float *dp, const float *grid,
+                               const int32_t *n_g, const int32_t *in_flags, const int32_t *nearest_cell,
+                               const int32_t *sensed_index, float *act, void *stream);
+
+/*
  * Formation metrics of the wrapper (assembly_wrapper.py:48-165, get_formation_metrics :167-187) for the
  * current positions of every environment, evaluated in double with the reference's definitions:
  *   metrics [E][5] double = { coverage_rate (:48-72), distribution_uniformity (:74-101),

@@ -29,7 +29,7 @@ class AsmParams(C.Structure):
 EXPORTS = ["_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
            "asm_default_params", "asm_obs_dim", "asm_abi_version", "asm_last_error", "asm_device_count",
            "asm_batch_observe_f32", "asm_batch_step_f32", "asm_batch_reset_f32",
-           "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_replay_gather_f32", "asm_replay_draw_indices",
+           "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_batch_rule_actions_f32", "asm_replay_gather_f32", "asm_replay_draw_indices",
            "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err"]
 
 _lib = None
@@ -66,6 +66,8 @@ def load() -> C.CDLL:
     lib.asm_batch_reset_f32.argtypes = [PP, u64, u32, i64, i32, i32] + [vp] * 16 + [vp]
     lib.asm_batch_random_actions_f32.restype = C.c_int
     lib.asm_batch_random_actions_f32.argtypes = [u64, u32, i64, i32, i32, vp, vp]
+    lib.asm_batch_rule_actions_f32.restype = C.c_int
+    lib.asm_batch_rule_actions_f32.argtypes = [PP, i32] + [vp] * 8 + [vp]
     lib.asm_batch_metrics_f64.restype = C.c_int
     lib.asm_batch_metrics_f64.argtypes = [PP, i32, vp, vp, vp, vp, vp]
     lib.asm_replay_gather_f32.restype = C.c_int

@@ -178,6 +178,20 @@ class BatchedAssemblyEnv:
         _lib.check(rc, "asm_batch_random_actions_f32")
         return out
 
+    def rule_actions(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(E, 2, n_a) actions of the reference's 'rule' expert (assembly.py:525-596) for the current state, i.e.
+        the state of the last reset()/step()/observe().  Needs keep_indices=True (the sensed lists)."""
+        if self.sensed_index is None:
+            raise RuntimeError("rule_actions needs the sensed-index lists: construct with keep_indices=True")
+        if out is None:
+            out = torch.empty(self.E, 2, self.n_a, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_rule_actions_f32(
+                C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), _ptr(self.grid_center), _ptr(self.n_g),
+                _ptr(self.in_flags), _ptr(self.nearest_cell), _ptr(self.sensed_index), _ptr(out), self._stream())
+        _lib.check(rc, "asm_batch_rule_actions_f32")
+        return out
+
     METRIC_FIELDS = ("coverage_rate", "distribution_uniformity", "voronoi_uniformity", "num_collisions",
                      "avg_distance_to_target")
 

@@ -298,6 +298,18 @@ int asm_batch_random_actions_f32(uint64_t seed, uint32_t step, int64_t env0, int
     return rc ? hip_fail(rc, "asm_batch_random_actions_f32") : 0;
 }
 
+int asm_batch_rule_actions_f32(const asm_params *prm, int E, const float *p, const float *dp, const float *grid,
+                               const int32_t *n_g, const int32_t *in_flags, const int32_t *nearest_cell,
+                               const int32_t *sensed_index, float *act, void *stream)
+{
+    DevParams P;
+    if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
+    if (!p || !dp || !grid || !n_g || !in_flags || !nearest_cell || !sensed_index || !act)
+        return fail(1, "asm_batch_rule_actions_f32: NULL pointer (the sensed-index list is required)");
+    int rc = asmenv::launch_rule_actions(P, p, dp, grid, n_g, in_flags, nearest_cell, sensed_index, act, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_rule_actions_f32") : 0;
+}
+
 int asm_batch_metrics_f64(const asm_params *prm, int E, const float *p, const float *grid, const int32_t *n_g,
                           double *metrics, void *stream)
 {

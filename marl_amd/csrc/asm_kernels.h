@@ -61,6 +61,8 @@ int launch_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, 
 int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ring, const float *act_ring,
                          const float *prior_ring, const float *rew_ring, const int64_t *index, int N, float *obs_out,
                          float *act_out, float *rew_out, float *next_out, float *prior_out, hipStream_t st);
+int launch_rule_actions(const DevParams &P, const float *p, const float *dp, const float *grid, const int *n_g,
+                        const int *inflags, const int *nearest, const int *sensed, float *act, hipStream_t st);
 int launch_metrics(int E, int n_a, int NGP, double r_avoid, double size_a, const float *p, const float *grid,
                    const int *n_g, double *out, hipStream_t st);
 int launch_sqrt(const double *in, double *out, int n, hipStream_t st);

@@ -1858,6 +1858,71 @@ __global__ void k_replay_gather(int E, int n_a, int obs_dim, int T, const float 
     if (lane == 2) rew_out[k] = rew_ring[(size_t)q * n_a + i];
 }
 
+// The 'rule' expert of ENV:525-596 for every agent of every environment, on the state the last observation was
+// taken of (its in-shape flags, nearest cells and sensed lists are inputs): entering velocity towards the nearest
+// cell when outside the shape, exploration velocity = 15 x the psi-weighted mean offset of the listed cells,
+// interaction velocity from all agents inside d_sen; the sum clipped to [-1, 1].  One workgroup per environment,
+// one lane per agent, double precision in the reference's order of operations.
+__global__ void __launch_bounds__(1024) k_rule_actions(DevParams P, const float *p_g, const float *dp_g, const float *grid_g,
+                                                       const int *ng_g, const int *inflag_g, const int *nearest_g,
+                                                       const int *sensed_g, float *act_g)
+{
+    __shared__ float spx[ASM_MAX_AGENTS], spy[ASM_MAX_AGENTS], svx[ASM_MAX_AGENTS], svy[ASM_MAX_AGENTS];
+    const int e = blockIdx.x, n_a = P.n_a, cap = P.n_obs, NG = P.n_g_max;
+    const float *gx = grid_g + (size_t)e * 2 * NG, *gy = gx + NG;
+    const size_t o = (size_t)e * 2 * n_a;
+    for (int j = threadIdx.x; j < n_a; j += blockDim.x) {
+        spx[j] = p_g[o + j]; spy[j] = p_g[o + n_a + j]; svx[j] = dp_g[o + j]; svy[j] = dp_g[o + n_a + j];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= n_a) return;
+    const double px = spx[i], py = spy[i], vx = svx[i], vy = svy[i];
+    const double k_1 = 1, k_2 = 15, k_3 = 17;                                   // ENV:527
+    double a0 = 0.0, a1 = 0.0;
+    if (!inflag_g[(size_t)e * n_a + i]) {                                       // ENV:531-536
+        const int c = nearest_g[(size_t)e * n_a + i];
+        const double tx = (double)gx[c] - px, ty = (double)gy[c] - py;
+        const double tn = sqrt(tx * tx + ty * ty) + 1e-8;
+        a0 = k_1 * (tx / tn) + (0.0 - vx); a1 = k_1 * (ty / tn) + (0.0 - vy);
+    }
+    {                                                                           // ENV:569-579
+        const int *sl = sensed_g + ((size_t)e * n_a + i) * cap;
+        double num0 = 0.0, num1 = 0.0, den = 0.0; int n = 0;
+        for (int k = 0; k < cap; ++k) {
+            const int c = sl[k];
+            if (c < 0) break;
+            const double g0 = (double)gx[c] - px, g1 = (double)gy[c] - py;
+            const double psi = reward_weight(P, sqrt(g0 * g0 + g1 * g1));
+            num0 += psi * g0; num1 += psi * g1; den += psi; ++n;
+        }
+        if (n > 0) {
+            if (den == 0) den = 1e-8;
+            a0 = a0 + k_2 * num0 / den; a1 = a1 + k_2 * num1 / den;
+        }
+    }
+    {                                                                           // ENV:582-593
+        int near = 0;
+        for (int j = 0; j < n_a; ++j) {
+            const double rx = (double)spx[j] - px, ry = (double)spy[j] - py;
+            near += (j != i && sqrt(rx * rx + ry * ry) < P.d_sen) ? 1 : 0;
+        }
+        double w0 = 0.0, w1 = 0.0;
+        for (int j = 0; j < n_a; ++j) {
+            const double rx = (double)spx[j] - px, ry = (double)spy[j] - py;
+            const double nr = sqrt(rx * rx + ry * ry);
+            if (j == i || !(nr < P.d_sen)) continue;
+            if (nr < P.r_avoid) {
+                const double f = -k_3 * (P.r_avoid / nr - 1);
+                w0 += f * rx; w1 += f * ry;
+            }
+            w0 += 5 * ((double)svx[j] - vx) / near; w1 += 5 * ((double)svy[j] - vy) / near;
+        }
+        a0 = a0 + w0; a1 = a1 + w1;
+    }
+    act_g[o + i] = (float)fmin(fmax(a0, -1.0), 1.0); act_g[o + n_a + i] = (float)fmin(fmax(a1, -1.0), 1.0);   // ENV:596
+}
+
 // Formation metrics of WRAP:48-165 for the given positions, one workgroup per environment, all in double with
 // the reference's definitions (distances are norms, i.e. square roots; argmin/min keep the first minimum; sums
 // run left to right).  out[e] = {coverage_rate, distribution_uniformity, voronoi_uniformity, contact pairs,
@@ -2192,6 +2257,16 @@ int launch_cos_f32_err(uint32_t lo, uint32_t hi, double *out_max, hipStream_t st
     const unsigned blocks = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 64);
     hipLaunchKernelGGL(k_cos_f32_err, dim3(blocks), dim3(256), 0, st, lo, hi, reinterpret_cast<unsigned long long *>(out_max));
     return (int)hipGetLastError();
+}
+
+int launch_rule_actions(const DevParams &P, const float *p, const float *dp, const float *grid, const int *n_g,
+                        const int *inflags, const int *nearest, const int *sensed, float *act, hipStream_t st)
+{
+    const int threads = (P.n_a + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_rule_actions, dim3((unsigned)P.E), dim3(threads), 0, st, P, p, dp, grid, n_g, inflags, nearest,
+                       sensed, act);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_metrics(int E, int n_a, int NGP, double r_avoid, double size_a, const float *p, const float *grid,

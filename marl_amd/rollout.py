@@ -140,6 +140,21 @@ def eval_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, episode_length: 
     return metrics, total
 
 
+def collect_expert_episode(env: BatchedAssemblyEnv, replay: DeviceReplay, episode_length: int):
+    """eval/collect_expert_data.py:58-77 for E environments: one episode driven by the in-environment 'rule'
+    expert (assembly.py:525-596), every transition (obs, expert action, next obs) landing in the replay slot the
+    environment steps into.  The environment must keep its index lists (keep_indices=True).  Returns the episode
+    statistics vector, reduced over the ranks."""
+    replay.begin_episode()
+    env.reset()
+    for _ in range(episode_length):
+        a = replay.action_slot()
+        env.rule_actions(out=a)
+        env.step(a)
+        replay.advance()
+    return reduce_episode_stats(env.episode_stats())
+
+
 def train_phase(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceReplay, batch_size: int = 2048,
                 num_updates: Optional[int] = None):
     """train_assembly.py:141-157."""

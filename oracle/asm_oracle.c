@@ -544,6 +544,72 @@ void oracle_env_step(const oracle_cfg *c, double *p, double *dp, const float *ac
 }
 
 /* ------------------------------------------------------------------------- */
+/* ENV:525-596, the 'rule' expert: entering + exploration + interaction velocities of
+ * every agent on the current state, clipped to [-1, 1].  Sums run left to right
+ * (numpy sums pairwise: compare with a tolerance). */
+void oracle_rule_actions(const oracle_cfg *c, const double *p, const double *dp, const double *grid,
+                         int n_g, double l_cell, double *act)
+{
+    const int n = c->n_a, cap = c->num_obs_grid_max;
+    const double k_1 = 1, k_2 = 15, k_3 = 17;                               /* ENV:527 */
+    double *norm_g = (double *)malloc(sizeof(double) * (size_t)(n_g > 0 ? n_g : 1));
+    int *sensed = (int *)malloc(sizeof(int) * (size_t)(n_g > 0 ? n_g : 1));
+    double *norm_a = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double px = p[i], py = p[n + i];
+        int in_flag, ns = 0;
+        const int mi = target_grid_state(i, p, n, grid, n_g, l_cell, c->d_sen, norm_g, &in_flag, sensed, &ns);  /* ENV:833-849 */
+        double v0 = 0, v1 = 0;
+        if (!in_flag) {                                                     /* ENV:531-536 */
+            const double tx = grid[mi] - px, ty = grid[n_g + mi] - py;
+            const double tn = norm2(tx, ty) + 1e-8;
+            v0 = k_1 * (tx / tn) + (0.0 - dp[i]); v1 = k_1 * (ty / tn) + (0.0 - dp[n + i]);
+        }
+        for (int j = 0; j < n; ++j) norm_a[j] = norm2(p[j] - px, p[n + j] - py);
+        if (ns > 0 && in_flag) {                                            /* ENV:542-553 */
+            for (int j = 0; j < n; ++j) {
+                if (!(norm_a[j] < c->d_sen + c->r_avoid / 2)) continue;
+                int m = 0;
+                for (int k = 0; k < ns; ++k) {
+                    const int g = sensed[k];
+                    if (norm2(grid[g] - p[j], grid[n_g + g] - p[n + j]) > c->r_avoid / 2) sensed[m++] = g;
+                }
+                ns = m;
+            }
+        }
+        const int n_out = ns > cap ? cap : ns;                              /* ENV:556-567 */
+        const double step = ns > cap ? (double)(ns - 1) / (cap - 1) : 1.0;
+        double e0 = 0, e1 = 0;
+        if (n_out > 0) {                                                    /* ENV:569-579 */
+            double num0 = 0, num1 = 0, den = 0;
+            for (int k = 0; k < n_out; ++k) {
+                const int g = sensed[ns > cap ? (int)nearbyint(k * step) : k];          /* np.round: half to even */
+                const double gx = grid[g] - px, gy = grid[n_g + g] - py;
+                const double psi = rho_cos_dec(norm2(gx, gy), 0, c->d_sen);
+                num0 += psi * gx; num1 += psi * gy; den += psi;
+            }
+            if (den == 0) den = 1e-8;
+            e0 = k_2 * num0 / den; e1 = k_2 * num1 / den;
+        }
+        int near = 0;                                                       /* ENV:582-593 */
+        for (int j = 0; j < n; ++j) near += j != i && norm_a[j] < c->d_sen;
+        double w0 = 0, w1 = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j == i || !(norm_a[j] < c->d_sen)) continue;
+            const double rx = p[j] - px, ry = p[n + j] - py;
+            if (norm_a[j] < c->r_avoid) {
+                const double f = -k_3 * (c->r_avoid / norm_a[j] - 1);
+                w0 += f * rx; w1 += f * ry;
+            }
+            w0 += 5 * (dp[j] - dp[i]) / near; w1 += 5 * (dp[n + j] - dp[n + i]) / near;
+        }
+        const double a0 = v0 + e0 + w0, a1 = v1 + e1 + w1;                  /* ENV:595-596 */
+        act[i] = a0 < -1 ? -1 : a0 > 1 ? 1 : a0; act[n + i] = a1 < -1 ? -1 : a1 > 1 ? 1 : a1;
+    }
+    free(norm_g); free(sensed); free(norm_a);
+}
+
+/* ------------------------------------------------------------------------- */
 /* WRAP:48-72 */
 double oracle_coverage_rate(const double *p, int n_a, const double *grid, int n_g, double r_avoid)
 {

@@ -107,6 +107,10 @@ void oracle_env_observe(const oracle_cfg *c, const double *p, const double *dp,
                         int *occupied_index);
 
 /* ---- formation metrics, WRAP = cus_gym/gym/wrappers/customized_envs/assembly_wrapper.py ---- */
+/* ENV:525-596: actions (2, n_a) of the 'rule' expert on the given state */
+void oracle_rule_actions(const oracle_cfg *c, const double *p, const double *dp, const double *grid,
+                         int n_g, double l_cell, double *act);
+
 double oracle_coverage_rate(const double *p, int n_a, const double *grid, int n_g, double r_avoid); /* WRAP:48-72 */
 double oracle_distribution_uniformity(const double *p, int n_a);                                   /* WRAP:74-101 */
 double oracle_voronoi_uniformity(const double *p, int n_a, const double *grid, int n_g);           /* WRAP:103-129 */

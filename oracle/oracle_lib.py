@@ -204,6 +204,13 @@ def env_step(cfg, p, dp, act, grid, l_cell, nbr):
     return obs, rew, ap, inf, sen, occ, co
 
 
+def rule_actions(cfg, p, dp, grid, l_cell):
+    """ENV:525-596 on the given state -> (2, n_a) float64."""
+    act = np.zeros((2, cfg.n_a))
+    lib().oracle_rule_actions(C.byref(cfg), d(p), d(dp), d(grid), C.c_int(grid.shape[1]), C.c_double(l_cell), d(act))
+    return act
+
+
 def philox(ctr, key):
     c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
     lib().oracle_philox4x32(c, k, o)

@@ -113,3 +113,40 @@ def test_eval_episode_with_shape_schedule(torch_cuda):
         obs, rew = env2.step(learner.act(obs, a))[:2]
         tot += rew.sum(dim=(1, 2), dtype=torch.float64)
     assert torch.equal(tot, total)
+
+
+@pytest.mark.parametrize("n_a,E", [(30, 12), (10, 5), (100, 3)])
+def test_rule_expert_actions_match_oracle(torch_cuda, n_a, E):
+    """asm_batch_rule_actions_f32 (assembly.py:525-596) against the oracle's restatement on the device's own state,
+    in the random and the packed regime, and over an episode driven by the expert itself (agents converge into
+    the shapes: entering, exploration with the occupancy filter and sub-sampling, interaction all get used).
+    Values: 1e-5 relative (device cos vs glibc, summation order) + one float32 rounding."""
+    torch = torch_cuda
+    import oracle_lib as ol
+    from marl_amd.batched import BatchedAssemblyEnv
+    from gpu_util import cfg_from_env
+    env = BatchedAssemblyEnv(E, n_a, seed=40 + n_a, keep_indices=True)
+    cfg = cfg_from_env(env)
+    env.reset()
+    rng = np.random.default_rng(n_a)
+    grid = env.grid_center.cpu().numpy(); n_g = env.n_g.cpu().numpy(); l_cell = env.l_cell.cpu().numpy()
+    p = env.p.cpu().numpy()
+    for e in range(0, E, 2):
+        p[e] = grid[e][:, rng.choice(n_g[e], n_a, replace=n_a > n_g[e])] + rng.normal(0, 0.04, (2, n_a))
+    env.p.copy_(torch.from_numpy(p)); env.observe()
+    clipped = inner = 0
+    for t in range(12):
+        a = env.rule_actions()
+        got = a.cpu().numpy().astype(np.float64)
+        P = env.p.cpu().numpy().astype(np.float64); V = env.dp.cpu().numpy().astype(np.float64)
+        for e in range(E):
+            g = np.ascontiguousarray(grid[e][:, :n_g[e]], dtype=np.float64)
+            want = ol.rule_actions(cfg, np.ascontiguousarray(P[e]), np.ascontiguousarray(V[e]), g, float(l_cell[e]))
+            np.testing.assert_allclose(got[e], want, rtol=1e-5, atol=2e-7, err_msg=f"n_a {n_a} step {t} env {e}")
+            clipped += int((np.abs(want) == 1).sum()); inner += int((np.abs(want) < 1).sum())
+        env.step(a)
+    assert clipped > 0 and inner > 0
+    plain = BatchedAssemblyEnv(2, n_a)
+    plain.reset()
+    with pytest.raises(RuntimeError, match="keep_indices"):
+        plain.rule_actions()

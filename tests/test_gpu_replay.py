@@ -87,3 +87,32 @@ def test_rollout_and_update_loop_runs(torch_cuda):
         assert len(losses) == 3 and all(np.isfinite(v) for pair in losses for v in pair)
     assert any(not torch.equal(a, b) for a, b in zip(before, learner.policy.parameters()))
     assert learner.niter == 6
+
+
+def test_expert_collection_fills_the_replay(torch_cuda):
+    """collect_expert_episode: the rule expert drives the environments and its transitions are what the replay
+    returns; over an episode the expert brings agents into their shapes (reward and coverage grow)."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.replay import DeviceReplay
+    from marl_amd.rollout import collect_expert_episode
+    from marl_amd.sharding import summarize
+    E, n_a, T = 12, 30, 60
+    env = BatchedAssemblyEnv(E, n_a, seed=8, keep_indices=True)
+    rp = DeviceReplay(env, episode_length=T, slots=1)
+    stats = summarize(collect_expert_episode(env, rp, T), n_a)
+    assert len(rp) == T * E * n_a
+    assert stats["inside_fraction"] > 0.3 and stats["coverage"] > 0.05
+    obs, acs, rews, nxt, dones, prior = rp.sample(4096)
+    assert acs.abs().max().item() <= 1.0 and (acs.abs() == 1).any() and (acs.abs() < 1).any()
+    assert not dones.any()
+    # the expert's last action is reproducible from the state before the last step: replay one short episode by hand
+    env2 = BatchedAssemblyEnv(E, n_a, seed=8, keep_indices=True)
+    env2.reset(0)
+    for _ in range(5):
+        a = env2.rule_actions()
+        env2.step(a)
+    env3 = BatchedAssemblyEnv(E, n_a, seed=8, keep_indices=True)
+    rp3 = DeviceReplay(env3, episode_length=5, slots=1)
+    collect_expert_episode(env3, rp3, 5)
+    assert torch.equal(env3.p, env2.p) and torch.equal(env3.obs, env2.obs)

@@ -124,3 +124,29 @@ def test_lattice_state_against_reference_except_tie_order():
             assert np.array_equal(d[i, na[:k]], d[i, nb[:k]]), (shape, i)                      # same distances, same order
             tied_orders += int(not np.array_equal(na, nb))
     assert tied_orders > 0          # the state does exercise the unspecified case
+
+
+def test_rule_expert_against_reference_env():
+    """agent_strategy='rule' (assembly.py:525-596): the reference computes the expert's action inside step() and
+    does not return it, so the oracle's restatement is checked through the state it leads to -- oracle action
+    (rounded to the float32 the oracle's step takes) + oracle dynamics against the reference's next state.  An
+    action error d moves dp by 0.1 d; the float32 rounding of the action accounts for at most 6e-9."""
+    np.random.seed(5)
+    n_a = 30
+    env = ref_env.make_ref_env(n_a=n_a, agent_strategy="rule")
+    e = env.env
+    env.reset()
+    cfg = ol.make_cfg(n_a=n_a, r_avoid=e.r_avoid)
+    grid = np.ascontiguousarray(e.grid_center)
+    moved = 0.0
+    for t in range(60):
+        p = np.ascontiguousarray(e.p.copy()); dp = np.ascontiguousarray(e.dp.copy())
+        nbr = np.ascontiguousarray(e.neighbor_index.copy())
+        a = ol.rule_actions(cfg, p, dp, grid, e.l_cell)
+        assert np.abs(a).max() <= 1.0
+        env.step(np.zeros((2, n_a), np.float32))                       # the argument is ignored in this mode
+        ol.env_step(cfg, p, dp, a.astype(np.float32), grid, e.l_cell, nbr)
+        np.testing.assert_allclose(dp, e.dp, rtol=0, atol=2e-8, err_msg=f"dp after step {t}")
+        np.testing.assert_allclose(p, e.p, rtol=0, atol=2e-9, err_msg=f"p after step {t}")
+        moved += np.abs(a).sum()
+    assert moved > 100                                                  # the expert does act
