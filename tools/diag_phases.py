@@ -63,6 +63,11 @@ slow = np.argsort(-wall)[:5]
 print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
 names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
          "cell pass", "in-flag, popcounts, target block", "sensed emission", "reward", "stats"]
+if b[:, 12].any():          # the multi-wave kernel stamps the same slots at its own phase boundaries (first wave's view)
+    names = ["P0 grids and state -> LDS", "P1 dynamics (first wave) / prior (second wave)", "P2 state write, two barriers",
+             "P3 k-NN + agent block (first wave)", "P3 the first wave's share of the cell words",
+             "barrier, P4 nearest cell, barrier, P5 slot lists", "barrier, P6 emission + reward weights",
+             "P7 reward", "P7 reward statistics"]
 tot = acc.sum(1).mean()
 print(f"workgroups {acc.shape[0]}, mean cycles per workgroup {tot:.0f}; last launch: mean workgroup lifetime {wall.mean():.1f} us, "
       f"first start -> last end {span:.1f} us => about {wall.sum() / span / 256:.1f} workgroups resident per CU, "
