@@ -1,0 +1,783 @@
+// k_step_fast<T>: the multi-wave step kernel for fp32 state, n_a <= 32, walls on.
+// Part of the single translation unit asm_kernels.hip (included there, inside namespace asmenv, after the
+// diagnostic macros); not a stand-alone header.
+
+// =====================================================================================
+// k_step_fast<T>: the step kernel for the common shape of the problem — fp32 state, at most 32
+// agents per environment, walls on (no periodic wrap), at most 1024 grid cells, n_g_max a
+// multiple of 32.  Same results as k_step<float> (the tests compare them bit for bit); the
+// difference is the schedule:
+//   * a workgroup = T wavefronts (T = 1, 2, 4) working on TWO environments; lane l of every
+//     wavefront is agent (l & 31) of environment (l >> 5), so all T waves see the same agents
+//     and every "which wave does what" branch is wave-uniform;
+//   * the agent x cell pass is split over the T waves by 32-cell words; the sensed-cell lists
+//     are compacted into LDS by words (ranks from per-word popcounts) and the 80 observation
+//     slots are then written slot-range by slot-range, every store a full row segment;
+//   * pair loops (contacts, k-NN) screen all 32 candidates in fp32 into a bit mask and run the
+//     exact double evaluation only on the set bits.
+// T is chosen by the host so that a launch has enough waves to fill the chip.
+struct FastLds {
+    float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
+    float *g;                      // x rows of the two environments at [0, 2 NGP), their y rows ASM_GY_OFF floats further on
+                                   // (a compile-time distance: one address serves both coordinates of a cell); cells >= n_g hold 1e30
+    unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
+    unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
+    uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
+    unsigned *fin;                 // [64]         nearest cell | in_flag << 31
+    float *rpart;                  // [T][3][64]   per-wave partial reward sums
+    unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
+};
+
+__device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T)
+{
+    FastLds L;
+    float *f = reinterpret_cast<float *>(smem);
+    L.px = f; L.py = f + 64; L.vx = f + 128; L.vy = f + 192;
+    L.g = f + 256;
+    L.mask = reinterpret_cast<unsigned *>(L.g + ASM_GY_OFF + 2 * P.NGP);
+    L.occ = L.mask + 64 * P.MW;
+    L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
+    L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
+    L.rpart = reinterpret_cast<float *>(L.fin + 64);
+    L.sel = reinterpret_cast<unsigned short *>(L.rpart + 3 * 64 * T);
+    return L;
+}
+
+// sum / min / max over the 32 lanes of an environment half
+__device__ __forceinline__ double half_sum(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+    return v;
+}
+__device__ __forceinline__ double half_min(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 32));
+    return v;
+}
+__device__ __forceinline__ double half_max(double v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 32));
+    return v;
+}
+
+// psi(z) of the reward's weighted mean (CPP:1017-1025 with delta = 0), the reference's expression
+__device__ __forceinline__ double reward_weight(const DevParams &P, double z)
+{
+    if (z < 0.0 * P.d_sen) return 1.0;
+    if (z < P.d_sen) return (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+    return 0.0;
+}
+
+#ifndef ASM_W0_LESS
+#define ASM_W0_LESS 2        // words wave 0 gives up in the cell pass because it also runs the k-NN pass
+#endif
+#ifndef ASM_FAST_MINW
+#define ASM_FAST_MINW 1
+#endif
+template <int T>
+__global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
+                                                      const float *grid_g, const int *ng_g, const double *lcell_g,
+                                                      int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
+                                                      float *rew_g, float *prior_g, int *sensed_g, int *occup_g,
+                                                      double *stats_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // sub is the same for every lane of a wave: read through the scalar unit so that everything derived from
+    // it (word and slot ranges, row offsets) stays in scalar registers
+    const int tid = threadIdx.x, sub = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, es = l >> 5, i = l & 31;
+    const int e = blockIdx.x * 2 + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
+    const FastLds L = carve_fast(smem, P, T);
+    float *gxe = L.g + (size_t)es * NGP, *gye = gxe + ASM_GY_OFF;
+    unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
+    constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
+    STAMP(0);
+#ifdef ASM_DIAG
+    if (g_diag && l == 0) g_diag[(size_t)blockIdx.x * 32 + 20 + sub] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID of this wave
+#endif
+
+#ifdef ASM_EXITS
+    const int xat = g_exit_at;
+#else
+    constexpr int xat = 0;
+#endif
+    // ---- P0: grid and state into LDS (all global loads issued before the first LDS write) ----
+    const int e0 = blockIdx.x * 2;
+    const int ng0 = e0 < P.E ? ng_g[e0] : 0, ng1 = e0 + 1 < P.E ? ng_g[e0 + 1] : 0;
+    const int n_g = es ? ng1 : ng0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    {
+        float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
+        if (sub == 0 && active) {
+            const size_t o = (size_t)e * 2 * n_a;
+            sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
+        }
+        // The four coordinate rows (2 environments x {x, y}) are dealt out to the waves, so the row and its n_g are
+        // wave-uniform and a lane's float4 index is just l, l + 64, ...; cells beyond n_g become far-away padding.
+        for (int row = sub; row < 4; row += T) {
+            const int h = row >> 1, ngh = h ? ng1 : ng0;
+            const bool row_ok = e0 + h < P.E;
+            const float *src = grid_g + ((size_t)(e0 + h) * 2 + (row & 1)) * NGP;
+            float *dst = L.g + (size_t)(row & 1) * ASM_GY_OFF + (size_t)h * NGP;
+            for (int base = 0; base < NGP; base += 64 * 4 * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = base + (q * 64 + l) * 4;
+                    v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                    if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = base + (q * 64 + l) * 4;
+                    if (base + q * 256 < NGP && c < NGP) {
+                        float4 u = v[q];
+                        if (c + 3 >= ngh) {                         // only the last cells of a row lie beyond n_g
+                            if (c + 0 >= ngh) u.x = 1e30f;
+                            if (c + 1 >= ngh) u.y = 1e30f;
+                            if (c + 2 >= ngh) u.z = 1e30f;
+                            u.w = 1e30f;
+                        }
+                        *reinterpret_cast<float4 *>(dst + c) = u;
+                    }
+                }
+            }
+        }
+        for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
+        if (sub == 0) { L.px[l] = sa; L.py[l] = sb; L.vx[l] = sc; L.vy[l] = sd; }
+    }
+    __syncthreads();
+    STAMP(1);
+    EXIT_AT(1);
+
+    int contacts = 0;
+    if (!P.observe_only) {                                          // reset / observe: the state is taken as it is
+    float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
+    // ---- P1: forces, prior and integration on the OLD state (ENV:486-647) -------------
+    if (sub == 0 && active) {
+        const float pxf = L.px[l], pyf = L.py[l];
+        const double px = pxf, py = pyf, vx = L.vx[l], vy = L.vy[l];
+        unsigned cc = 0;                                            // fp32 screen of the 32 slots
+#pragma unroll
+        for (int j4 = 0; j4 < 32; j4 += 4) {
+            const float4 X = *reinterpret_cast<const float4 *>(L.px + es * 32 + j4);
+            const float4 Y = *reinterpret_cast<const float4 *>(L.py + es * 32 + j4);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rx = xs[r] - pxf, ry = ys[r] - pyf;
+                const float s = __builtin_fmaf(ry, ry, rx * rx);
+                cc = __builtin_amdgcn_alignbit(cc, __float_as_uint(s - P.Tcontact_hi_f), 31);
+            }
+        }
+        cc = __brev(cc) & ~(1u << i);
+        double fx = 0.0, fy = 0.0;                                  // ENV:437-452 + CPP:740-820, ascending k
+        while (cc) {
+            const int k = __ffs(cc) - 1; cc &= cc - 1;
+            const double dx = (double)L.px[es * 32 + k] - px, dy = (double)L.py[es * 32 + k] - py;   // CPP:782-785
+            const double s = dx * dx + dy * dy;                     // ENV:444
+            if (s < P.T_contact) {                                  // ENV:445-446
+                const double d = sqrt(s);
+                const double gap = fabs(d - P.sizes2);              // ENV:447
+                fx += 1.0 * gap * P.k_ball * (-(dx / d));           // CPP:790-793
+                fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                if (k > i) ++contacts;
+            }
+        }
+        // walls: CPP:822-860, ENV:510-513
+        const double r = P.size_a;
+        const double d0 = px - r - (-P.half_w), d1 = P.half_h - (py + r);       // CPP:841-842
+        const double d2 = P.half_w - (px + r), d3 = py - r - (-P.half_h);       // CPP:843-844
+        const bool c0 = d0 < 0, c1 = d1 < 0, c2 = d2 < 0, c3 = d3 < 0;          // CPP:849
+        const double a0 = c0 ? fabs(d0) : 0.0, a1 = c1 ? fabs(d1) : 0.0, a2 = c2 ? fabs(d2) : 0.0, a3 = c3 ? fabs(d3) : 0.0;
+        const double wfx = (a0 - a2) * P.k_wall, wfy = (-a1 + a3) * P.k_wall;   // ENV:512
+        const double dfx = (-(c0 ? vx : 0.0) + -(c2 ? vx : 0.0)) * P.c_wall;    // ENV:513
+        const double dfy = (-(c1 ? vy : 0.0) + -(c3 ? vy : 0.0)) * P.c_wall;
+        // integration: ENV:626-647
+        const float sens = (float)P.sens;
+        const double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);       // ENV:627,633
+        const double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        const double Fx = ux + fx + wfx + dfx, Fy = uy + fy + wfy + dfy;         // ENV:633
+        double ax = Fx, ay = Fy;
+        if (P.mass != 1.0) { ax = Fx / P.mass; ay = Fy / P.mass; }               // ENV:638 (x / 1 == x)
+        double v0 = vx + ax * P.dt, v1 = vy + ay * P.dt;                         // ENV:641
+        v0 = fmin(fmax(v0, -P.vel_max), P.vel_max); v1 = fmin(fmax(v1, -P.vel_max), P.vel_max);   // ENV:642
+        npx = (float)(px + v0 * P.dt); npy = (float)(py + v1 * P.dt);            // ENV:645
+        nvx = (float)v0; nvy = (float)v1;
+    }
+    if (sub == SUB_PRIOR && active && P.prior && prior_g) {         // ENV:600-619: old state, previous neighbour list
+        const double px = L.px[l], py = L.py[l], vx = L.vx[l], vy = L.vy[l];
+        int nb[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+        bool inf; int near;
+        if (P.recompute) {
+            double smin; cell_pass<float, false>(P, true, px, py, gxe, gye, l, nullptr, nullptr, nullptr, smin, near);
+            inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
+        } else {
+            inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
+        }
+        const double tx = inf ? px : (double)gxe[near], ty = inf ? py : (double)gye[near];      // CPP:896-901
+        double f0, f1;
+        prior_policy<float>(P, px, py, vx, vy, tx, ty, nb, L.px + es * 32, L.py + es * 32, L.vx + es * 32,
+                            L.vy + es * 32, f0, f1);
+        prior_g[(size_t)e * 2 * n_a + i] = (float)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (float)f1;
+    }
+    STAMP(2);
+    __syncthreads();                                                // all reads of the old state done
+    if (sub == 0 && active) {
+        L.px[l] = npx; L.py[l] = npy; L.vx[l] = nvx; L.vy[l] = nvy;
+        const size_t o = (size_t)e * 2 * n_a;
+        p_g[o + i] = npx; p_g[o + n_a + i] = npy; dp_g[o + i] = nvx; dp_g[o + n_a + i] = nvy;
+    }
+    __syncthreads();
+    }
+    STAMP(3);
+    EXIT_AT(2);
+
+    // ---- P3: agent x cell pass on the NEW state, words split over the waves ------------
+    const float pxf = L.px[l], pyf = L.py[l];
+    const double px = pxf, py = pyf;
+    // obs[row * n_a + agent] of this lane's environment, written with buffer stores: resource = the block of the
+    // workgroup's two environments, vector offset = the lane's column, scalar offset = the row; a row store then
+    // needs no vector address arithmetic
+    const __amdgpu_buffer_rsrc_t obs_rs =
+        __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e0 * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
+    const int olb = (es * P.obs_dim * n_a + i) * 4;
+    auto ostore = [&](int row, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, 0);
+    };
+    double s6[6]; int j6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
+    double nn_min = __builtin_inf();
+    if (sub == 0 && active && xat != 13) {
+        // k nearest neighbours inside d_sen (_get_focused, CPP:633-703): fp32 screen, exact on candidates
+        unsigned cand = 0, n1 = 0xFFFFFFFFu, n2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j4 = 0; j4 < 32; j4 += 4) {
+            const float4 X = *reinterpret_cast<const float4 *>(L.px + es * 32 + j4);
+            const float4 Y = *reinterpret_cast<const float4 *>(L.py + es * 32 + j4);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rx = xs[r] - pxf, ry = ys[r] - pyf;
+                const float s = __builtin_fmaf(ry, ry, rx * rx);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(s - P.Tsen_hi_f), 31);
+                const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)(j4 + r);   // two smallest: self (0)
+                n2 = umed3(n1, n2, key); n1 = n1 < key ? n1 : key;                        // and the nearest neighbour
+            }
+        }
+        cand = __brev(cand) & ~(1u << i);                           // self removed CPP:677-681
+        // The candidates' single-precision keys (s32 with the low 5 bits replaced by the index) go through a
+        // min/max insertion chain that keeps the 7 smallest in order.  The order of the first six -- among
+        // themselves and against the seventh, hence against everything else -- is certain when neighbouring keys
+        // differ by at least two units of 32 ulps (the screen is off by a few ulps), and a listed agent is
+        // certainly inside d_sen when its key lies two units below T_sen.  Otherwise (ties, near-ties, agents at
+        // the sensing range) the lane redoes its list in double below.
+        const unsigned cand_all = cand;
+        unsigned K[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
+        while (cand) {
+            const int j = __builtin_ctz(cand); cand &= cand - 1;
+            const float rx = L.px[es * 32 + j] - pxf, ry = L.py[es * 32 + j] - pyf;
+            unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~31u) | (unsigned)j;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+        }
+        const unsigned tlo = (__float_as_uint(P.Tsen_f) >> 5) - 2u;
+        bool redo = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const bool there = K[q] != 0xFFFFFFFFu;
+            const unsigned u = K[q] >> 5;
+            redo |= there && (u >= tlo || (K[q + 1] >> 5) - u < 2u);
+            j6[q] = there ? (int)(K[q] & 31u) : -1;
+        }
+        if (__ballot(redo)) {                                       // rare
+            if (redo) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) j6[q] = -1;
+                cand = cand_all;
+                while (cand) {                                      // ascending j: ties keep the lower index
+                    const int j = __ffs(cand) - 1; cand &= cand - 1;
+                    const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+                    const double s = dx * dx + dy * dy;             // CPP:641
+                    if (s < P.T_sen) {                              // CPP:663
+                        double ks = s; int kj = j; bool placed = false;     // once placed, the entries behind move down one place
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            if (placed || ks < s6[q]) { const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
+                    }
+                }
+            }
+        }
+        if (P.want_stats && n_a > 1) {
+            const int nj = (int)((n1 & 31u) == (unsigned)i ? (n2 & 31u) : (n1 & 31u));
+            const double dx = (double)L.px[es * 32 + nj] - px, dy = (double)L.py[es * 32 + nj] - py;
+            nn_min = dx * dx + dy * dy;
+        }
+        // agent block, rows [pos_x,pos_y,vel_x,vel_y] per column (CPP:108-131); fl32(a - b) is the
+        // correctly rounded difference, identical to rounding the double difference
+        const float vxf = L.vx[l], vyf = L.vy[l];
+        int r0 = 0;
+        if (P.con_self) { ostore(0, pxf); ostore(1, pyf); ostore(2, vxf); ostore(3, vyf); r0 = 4; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int j = j6[q];
+            float rx = 0.f, ry = 0.f, wx = 0.f, wy = 0.f;
+            if (j >= 0) {
+                rx = L.px[es * 32 + j] - pxf; ry = L.py[es * 32 + j] - pyf;
+                wx = L.vx[es * 32 + j] - vxf; wy = L.vy[es * 32 + j] - vyf;      // CPP:86
+            }
+            nbr_g[((size_t)e * n_a + i) * 6 + q] = j;               // CPP:103-105
+            const int r = r0 + 4 * q;
+            ostore(r, rx); ostore(r + 1, ry); ostore(r + 2, wx); ostore(r + 3, wy);
+        }
+    }
+    STAMP(4);
+    {
+        // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest
+        // s32 is tracked (two cells per v_min3_u32); which cell it belongs to, and whether another cell is too
+        // close to tell in single precision, is settled in P4 by screening the one word that holds it once more.
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;   // ambw: words with an undecided sensed bit
+        unsigned *wkey = reinterpret_cast<unsigned *>(L.sel);       // [64][MW], aliases the slot lists (written later)
+        const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+        const f32x2 thr = {P.Tsen_f, P.Thalf_f};
+        // wave 0 also runs the k-NN pass above, so it takes only the first W0 words; the others share the rest
+        const int W0 = T == 1 ? W : (W / T > ASM_W0_LESS ? W / T - ASM_W0_LESS : 0);
+        for (int w = (T == 1 || sub == 0) ? 0 : W0 + sub - 1; w < ((T == 1 || sub != 0) ? W : W0); w += (T == 1 || sub == 0) ? 1 : T - 1) {
+            unsigned k1 = 0xFFFFFFFFu, word = 0, ocand = 0;
+            float amb = __builtin_inff(), ambo = __builtin_inff();
+            const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
+            const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x4 = X[q], y4 = Y[q];
+                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                const float ss[4] = {sa.x, sa.y, sb.x, sb.y};
+                k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));   // s >= 0: the bit patterns order like the values
+                k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = ss[r];
+                    const f32x2 s2 = {s, s};
+                    const f32x2 d = s2 - thr;                                   // (s - T_sen, s - T_half)
+                    word = __builtin_amdgcn_alignbit(word, __float_as_uint(d.x), 31);
+                    ocand = __builtin_amdgcn_alignbit(ocand, __float_as_uint(d.y), 31);
+                    amb = __builtin_fminf(amb, __builtin_fabsf(d.x));
+                    ambo = __builtin_fminf(ambo, __builtin_fabsf(d.y));
+                }
+            }
+            L.mask[(size_t)l * MW + w] = __brev(word);
+            wkey[(size_t)l * MW + w] = k1;                           // smallest s32 of the word
+            if (!(amb > P.Tsen_amb_f)) ambw |= 1u << w;
+            settle_occupancy(P, active, __brev(ocand), ambo, px, py, gxe + w * 32, gye + w * 32, &occ_e[w], &cov_e[w]);
+            if (k1 < G1) G1w = (unsigned)w;                         // strict: the first word holding the smallest s32
+            G2 = umed3(G1, G2, k1);                                 // the two smallest word minima
+            G1 = G1 < k1 ? G1 : k1;
+        }
+        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, ambw);
+    }
+    STAMP(5);
+    __syncthreads();
+    STAMP(12);
+    EXIT_AT(3);
+
+    // ---- P4 (wave 0): nearest cell, in-shape flag, target block -------------------------
+    double dmin = 0.0;
+    if (sub == 0) {
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+            const uint4 q = L.part[s * 64 + l];
+            if (q.x < G1) G1w = q.z;
+            const unsigned t = G1 > q.x ? G1 : q.x, m = G2 < q.y ? G2 : q.y;
+            G2 = m < t ? m : t;
+            G1 = G1 < q.x ? G1 : q.x;
+            ambw |= q.w;
+        }
+        int imin = 0;
+        double smin = __builtin_inf();
+        if (active) {
+            // Candidates for the nearest cell: s32 within two units of 32 ulps of the smallest one (the screen's error
+            // is a few ulps).  They lie in the word of the smallest s32 and, rarely, in other words whose minimum is
+            // that close.  Those words are screened again (same arithmetic, so the same s32) and the candidates
+            // evaluated in double; ascending index + strict '<' gives the reference's first minimum (CPP:889).
+            const unsigned lo = G1 >> 5;
+            unsigned minw = 1u << G1w;
+            if (!((G2 >> 5) - lo >= 2u)) {
+                const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
+                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
+            }
+            const unsigned lim = (lo << 5) + 64u;                   // candidate <=> bits(s32) < lim
+            const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+            while (minw) {
+                const int w = __ffs(minw) - 1; minw &= minw - 1;
+                const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
+                const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
+                unsigned cand = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 x4 = X[q], y4 = Y[q];
+                    const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                    const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                    const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                    const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.x) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.y) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.x) - lim, 31);
+                    cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.y) - lim, 31);
+                }
+                cand = __brev(cand);
+                while (cand) {
+                    const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
+                    const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
+                    const double sd = dx * dx + dy * dy;
+                    if (sd < smin) { smin = sd; imin = c; }
+                }
+            }
+            if (ambw) {
+                // Rare: sensed bits within the margin of T_sen, decided in double
+                unsigned *mw = L.mask + (size_t)l * MW;
+                while (ambw) {
+                    const int w = __ffs(ambw) - 1; ambw &= ambw - 1;
+                    unsigned word = mw[w];
+#pragma unroll 4
+                    for (int b = 0; b < 32; ++b) {
+                        const int c = w * 32 + b;
+                        const float rx = gxe[c] - pxf, ry = gye[c] - pyf;
+                        const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+                        if (__builtin_fabsf(s32 - P.Tsen_f) <= P.Tsen_amb_f) {
+                            const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
+                            const double sd = dx * dx + dy * dy;
+                            if (sd < P.T_sen) word |= 1u << b; else word &= ~(1u << b);
+                        }
+                    }
+                    mw[w] = word;
+                }
+            }
+            dmin = sqrt(smin);
+            const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;     // CPP:894
+            L.fin[l] = (unsigned)imin | ((unsigned)contacts << 16) | (in_flag ? 0x80000000u : 0u);   // imin < 1024, contacts < 32
+            inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;        // CPP:139
+            nearest_g[(size_t)e * n_a + i] = imin;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
+            if (!in_flag) { t0 = gxe[imin] - pxf; t1 = gye[imin] - pyf; t2 = 0.f - L.vx[l]; t3 = 0.f - L.vy[l]; }
+            const int tb = P.obs_dim - (2 + cap) * 2;               // CPP:304
+            ostore(tb + 0, t0); ostore(tb + 1, t1);
+            ostore(tb + 2, t2); ostore(tb + 3, t3);
+        } else {
+            L.fin[l] = 0;
+        }
+        if (T > 1 && P.want_stats)                                  // wave 1 computes the formation statistics in P7
+            L.part[l] = make_uint4(__double2loint(dmin), __double2hiint(dmin), __double2loint(nn_min), __double2hiint(nn_min));
+    }
+    STAMP(13);
+    __syncthreads();
+    STAMP(14);
+    EXIT_AT(4);
+
+    // ---- P5: compaction of the sensed lists into LDS -----------------------------------
+    const unsigned fin = L.fin[l];
+    const bool in_flag = (fin >> 31) != 0;
+    const unsigned *mym = L.mask + (size_t)l * MW;
+    const unsigned inm = in_flag ? 0xFFFFFFFFu : 0u;                // CPP:155: occupied cells drop out only inside the shape
+    const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
+    // Unused lanes sit at -1e30 (P0), so their masks are empty.  The words whose first rank lies below k0 form a
+    // prefix of nb words; this wave starts at the first non-empty word after them, whose first rank is bst.
+    int n_after = 0, nb = 0, bst = 0;
+    unsigned nz = 0;                                                // words with a cell that stays in the list
+    for (int w = 0; w < W; ++w) {
+        const unsigned f = mym[w] & ~(occ_e[w] & inm);
+        const int pc = __popc(f);
+        const bool below = n_after < k0;
+        n_after += pc;
+        nb += below ? 1 : 0;
+        bst = below ? n_after : bst;
+        nz |= (unsigned)(pc < 1 ? pc : 1) << w;
+    }
+    const unsigned nzs = nb >= 32 ? 0u : nz & (0xFFFFFFFFu << nb);
+    const bool found = nzs != 0;
+    const int wst = found ? __ffs(nzs) - 1 : 0;
+    const int n_out = n_after < cap ? n_after : cap;
+    unsigned short *mysel = L.sel + (size_t)l * P.capp;
+    STAMP(16);
+    [[maybe_unused]] int diag_it = 0;
+    {
+        // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
+        // rank k.  One loop per lane over its own set bits; the wave iterates as often as its busiest lane.
+        if (__ballot(n_after > cap) == 0) {
+            // Common case, no lane of the workgroup sub-samples: slot == rank.  Wave `sub` lists the words
+            // whose first rank lies in [k0, k1) (found above, so it starts without skipping anything).  The
+            // lane's next QN non-empty words are fetched into registers in one batch, so the loop below runs
+            // without waiting on LDS; a lane that needs more words finishes in the second loop.
+            constexpr int QN = 6;
+            bool busy = found && bst < k1;
+            int rank = bst;
+            nz &= 0xFFFFFFFFu << wst;
+            unsigned fq[QN], wq = 0;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const bool has = nz != 0;
+                const int wi = has ? __ffs(nz) - 1 : 0;
+                nz &= nz - 1;                                       // stays 0 once empty
+                const unsigned f = mym[wi] & ~(occ_e[wi] & inm);
+                fq[q] = has ? f : 0u;
+                wq |= (unsigned)wi << (5 * q);
+            }
+            unsigned bits = fq[0];
+            busy = busy && bits != 0;
+            unsigned short *wp = mysel + rank, *const wend = mysel + k1;
+            unsigned wbase = (wq & 31u) << 5;
+            while (busy) {                                          // bits != 0 here; two cells of the word per trip
+                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
+                *wp = (unsigned short)(wbase | b);
+                // the word's next cell, if it has one, goes to the next slot in the same trip (no branch: without
+                // one the first cell is stored once more in place)
+                const bool two = bits != 0;
+                const unsigned b2 = (unsigned)(__ffs(bits) - 1); bits &= bits - 1;      // bits == 0 stays 0
+                wp[two ? 1 : 0] = (unsigned short)(wbase | (two ? b2 : b));
+                wp += two ? 2 : 1;
+                ++diag_it;
+                if (bits == 0) {
+#pragma unroll
+                    for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
+                    fq[QN - 1] = 0; wq >>= 5; wbase = (wq & 31u) << 5;
+                    bits = fq[0];
+                    if (bits == 0 || wp >= wend) busy = false;
+                }
+            }
+            rank = (int)(wp - mysel);
+            busy = found && rank < k1 && nz != 0;                   // rare: more than QN words in this wave's range
+            bits = 0;
+            int w = 0;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0 || rank >= k1) { busy = false; continue; }
+                    w = __ffs(nz) - 1; nz &= nz - 1;
+                    bits = mym[w] & ~(occ_e[w] & inm);
+                }
+                const int b = __ffs(bits) - 1; bits &= bits - 1;
+                mysel[rank++] = (unsigned short)(w * 32 + b);
+            }
+#ifdef ASM_DIAG
+            for (int m = 32; m >= 1; m >>= 1) diag_it = max(diag_it, __shfl_xor(diag_it, m, 64));
+            DIAG_COUNT(17, diag_it);
+#endif
+        } else {
+            DIAG_COUNT(18, 1);
+            // cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double evaluation
+            // rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced incrementally
+            // as quotient/remainder (increment exactly 1 for n <= cap).  Wave `sub` fills the slots [k0, k1).
+            const unsigned two_c = 2u * (unsigned)(cap - 1);
+            const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
+            const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
+            const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
+            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0, wbase = 0;
+            // t_{k0} >= k0, and the words before word nb - 1 end below rank k0: the walk starts at word nb - 1,
+            // whose first rank is bst minus its own count
+            const int w0 = nb > 0 ? nb - 1 : 0;
+            int rank = nb > 0 ? bst - __popc(mym[w0] & ~(occ_e[w0] & inm)) : 0;
+            nz &= 0xFFFFFFFFu << w0;
+            unsigned short *wp = mysel + k0, *const wend = mysel + (k1 < n_out ? k1 : n_out);
+            bool busy = active && k0 < n_out;
+            while (busy) {
+                if (bits == 0) {
+                    if (nz == 0) { busy = false; continue; }
+                    const int w = __builtin_ctz(nz); nz &= nz - 1;
+                    bits = mym[w] & ~(occ_e[w] & inm);
+                    wbase = (unsigned)w << 5;
+                    const int pc = __popc(bits);
+                    if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+                    for (int d = (int)tq - rank; d > 0; --d) bits &= bits - 1;             // so do its first tq - rank cells
+                    rank = rank < (int)tq ? (int)tq : rank;
+                }
+                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
+                if ((unsigned)rank == tq) {
+                    *wp++ = (unsigned short)(wbase | b);
+                    tq += inc_q; tr += inc_r;
+                    if (tr >= two_c) { tr -= two_c; ++tq; }
+                    if (wp >= wend) busy = false;
+                }
+                ++rank;
+            }
+        }
+    }
+    if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
+        int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
+        int n_occ_list = 0;
+        for (int w = 0; w < W; ++w) n_occ_list += __popc(mym[w] & occ_e[w]);
+        BitIter it; it.init(mym, W, occ_e, false);
+        emit_list(it, in_flag ? n_occ_list : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+    }
+    STAMP(6);
+    if (T > 1) __syncthreads();                                     // the lists are complete
+    STAMP(15);
+    EXIT_AT(5);
+
+    // ---- P6: the observation's cell block (CPP:279-296) + reward weights, slots split over the waves ----
+    const bool rew_on = active && in_flag && n_after > 0;
+    float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+    {
+        const int gb = P.obs_dim - cap * 2;
+        int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * cap : nullptr;
+        constexpr int RB = 10;                                      // slots per round: indices, coordinates, then math + stores
+        if (active) {
+            for (int kb = k0; kb < k1; kb += RB) {
+                int cell[RB]; float cx[RB], cy[RB]; bool have[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q];   // one batch of LDS reads; entries past k1 (the list is padded by RB) are masked below
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? cell[q] : 0; }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int k = kb + q;
+                    if (k < k1) {
+                        const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
+#ifndef ASM_EXP_NOSTORE
+                        ostore(gb + 2 * k, gx); ostore(gb + 2 * k + 1, gy);
+#endif
+                        if (sdst) sdst[k] = have[q] ? cell[q] : -1;
+                        // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
+                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float psi = have[q] ? __builtin_fmaf(0.5f, __builtin_amdgcn_cosf(z * P.inv2dsen_f), 0.5f) : 0.f;
+                        fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
+                    }
+                }
+            }
+        }
+        if (T > 1) { L.rpart[(sub * 3 + 0) * 64 + l] = fn0; L.rpart[(sub * 3 + 1) * 64 + l] = fn1; L.rpart[(sub * 3 + 2) * 64 + l] = fden; }
+    }
+    STAMP(7);
+    if (T > 1) __syncthreads();
+    EXIT_AT(6);
+
+    // ---- P7 (wave 0): reward (CPP:457-564) and per-environment statistics ---------------
+    if (sub == 0) {
+        double reward = 0.0;
+        bool collision = false, uniform = false, known = true;      // known: the reward's uniformity test is decided
+        if (active) {
+            if (T > 1) {
+                fn0 = 0.f; fn1 = 0.f; fden = 0.f;
+#pragma unroll
+                for (int s = 0; s < T; ++s) { fn0 += L.rpart[(s * 3 + 0) * 64 + l]; fn1 += L.rpart[(s * 3 + 1) * 64 + l]; fden += L.rpart[(s * 3 + 2) * 64 + l]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {                           // CPP:464-496
+                const int j = j6[q];
+                if (j >= 0) {
+                    const double rx = (double)L.px[es * 32 + j] - px, ry = (double)L.py[es * 32 + j] - py;
+                    if (rx * rx + ry * ry < P.T_ravoid) collision = true;   // CPP:487
+                }
+            }
+            if (rew_on) {
+                known = false;
+                if (fden > 0.f) {
+                    // Single-precision screen.  The weights psi carry an absolute error below 1e-6 (argument
+                    // rounding 2*pi*1.5e-7, v_cos_f32 below 5e-7, halved, plus one rounding), every term and
+                    // every accumulation step a relative rounding of 6e-8, so with n terms and |g| < d_sen
+                    // |v32 - v| < 0.64 n (1e-6 / den + 6e-8) + 1e-7 for the norm v of the mean offset; doubled here.
+                    const float rden = 1.0f / fden;
+                    const float v0 = fn0 * rden, v1 = fn1 * rden;
+                    const float vn = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                    const float margin = 1.28f * (float)n_out * __builtin_fmaf(1e-6f, rden, 6e-8f) + 2e-7f;
+                    if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; known = true; }
+                }
+            }
+        }
+        // Borderline agents: the reference's double-precision sums (CPP:515-552), one agent at a time with the
+        // 64 lanes sharing its slots.  The terms are the reference's; only their order of summation differs
+        // (relative error below 80 * 2^-53), so a result within 1e-11 of the threshold falls through to the
+        // sequential evaluation in the reference's order.
+        for (unsigned long long todo = __ballot(!known); todo; todo &= todo - 1) {
+            const int src = __ffsll(todo) - 1;
+            const int n_src = __builtin_amdgcn_readlane(n_out, src);
+            const double sx = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pxf), src));
+            const double sy = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pyf), src));
+            const unsigned short *ssel = L.sel + (size_t)src * P.capp;
+            const float *sgx = L.g + (size_t)(src >> 5) * NGP, *sgy = sgx + ASM_GY_OFF;
+            double num0 = 0.0, num1 = 0.0, den = 0.0;
+            for (int k = l; k < n_src; k += 64) {
+                const int cell = ssel[k];
+                const double gx = (double)sgx[cell] - sx, gy = (double)sgy[cell] - sy;           // CPP:515-516
+                const double psi = reward_weight(P, sqrt(gx * gx + gy * gy));                     // CPP:524
+                num0 += psi * gx; num1 += psi * gy; den += psi;                                  // CPP:537-539
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                num0 += __shfl_xor(num0, m, 64); num1 += __shfl_xor(num1, m, 64); den += __shfl_xor(den, m, 64);
+            }
+            if (l == src) {
+                if (den == 0) den = 1E-8;                           // CPP:542-544
+                const double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;                       // CPP:547-548
+                const double q = v0 * v0 + v1 * v1;
+                if (fabs(q - P.T_v005) > 1e-11 * P.T_v005) {
+                    uniform = q < P.T_v005;                         // CPP:550-552
+                } else {
+                    num0 = 0.0; num1 = 0.0; den = 0.0;
+                    for (int k = 0; k < n_out; ++k) {
+                        const int cell = mysel[k];
+                        const double gx = (double)gxe[cell] - px, gy = (double)gye[cell] - py;
+                        const double psi = reward_weight(P, sqrt(gx * gx + gy * gy));
+                        num0 += psi * gx; num1 += psi * gy; den += psi;
+                    }
+                    if (den == 0) den = 1E-8;
+                    const double w0 = 1.0 * num0 / den, w1 = 1.0 * num1 / den;
+                    uniform = w0 * w0 + w1 * w1 < P.T_v005;
+                }
+            }
+        }
+        if (active) {
+            if (in_flag && !collision && uniform) reward += 1.0;    // CPP:559-561
+            if (P.want_reward) rew_g[(size_t)e * n_a + i] = (float)reward;
+        }
+        STAMP(8);
+        if (P.want_stats) {                                         // TRAIN:128-131: reward sums, agents inside
+            const unsigned long long half = es ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+            const double rs = (double)__popcll(__ballot(active && reward > 0.0) & half), rq = rs;     // rewards are 0 or 1
+            const double inn = (double)__popcll(__ballot(active && in_flag) & half);
+            if (i == 0 && env_ok) {
+                double *st = stats_g + (size_t)e * 8;
+                st[0] += rs; st[1] += rq; st[7] += inn;
+            }
+        }
+    }
+    // Formation statistics (TRAIN:132-135; WRAP:48-165): they do not depend on the reward, so with several waves the
+    // second one computes them while the first evaluates the reward (its inputs were handed over through LDS in P4).
+    if (sub == SUB_PRIOR && P.want_stats) {
+        double dm = dmin, nn = nn_min; int cn = contacts;
+        if (T > 1) {
+            const uint4 q = L.part[l];
+            dm = __hiloint2double((int)q.y, (int)q.x); nn = __hiloint2double((int)q.w, (int)q.z);
+            cn = (int)((fin >> 16) & 0xFFu);
+        }
+        const double m = active ? sqrt(nn) : 0.0;
+        int ci = cn + (i < W ? __popc(cov_e[i]) << 16 : 0);                                           // two small sums in one word
+#pragma unroll
+        for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
+        const double cp = (double)(ci & 0xFFFF), covered = (double)(ci >> 16);
+        const double ds = half_sum(active ? dm : 0.0), ms = half_sum(m);
+        const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
+        const double mean = ms / n_a, dv = active ? m - mean : 0.0;
+        const double var = half_sum(dv * dv) / n_a;
+        if (i == 0 && env_ok) {
+            double *st = stats_g + (size_t)e * 8;
+            st[2] += covered / n_g;
+            st[3] += (var - lo) / (hi - lo);                        // WRAP:98-99
+            st[4] += cp; st[5] += ds / n_a; st[6] += 1.0;
+        }
+    }
+    STAMP(9);
+}
+

@@ -1,0 +1,606 @@
+// The generic kernels: observation + reward of one environment per (part of a) workgroup for any n_a <= 1024 and
+// both state types (observe<S>), k_observe, k_step, k_reset.
+// Part of the single translation unit asm_kernels.hip (included there, inside namespace asmenv, after the
+// diagnostic macros); not a stand-alone header.
+
+// ---------------------------------------------------------------------------------
+// Observation + reward of environment e for agent i on the state held in LDS.
+// CPP:23-356 (observation), CPP:359-631 (reward).  Must be reached by every thread.
+//
+// S = float takes single-precision screening paths wherever a decision is certain in
+// fp32 and falls back to the exact double evaluation otherwise (cell_pass_fast above;
+// the neighbour and reward screens below follow the same rule), so its decisions are
+// those of the all-double code; S = double is the all-double code.
+template <typename S>
+__device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, double l_cell,
+                        const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
+                        int *sensed_g, int *occup_g, double *stats_g, int contact_pairs)
+{
+    constexpr bool F32 = sizeof(S) == 4;
+    const int n_a = P.n_a;
+    // large swarms on fp32 state: pair loops screen 32 agents at a time, the cell pass settles undecided words only
+    const bool swarm = F32 && !P.periodic && P.SL >= 64;
+    const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
+    const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
+    S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
+
+    // ---- k nearest neighbours inside d_sen: _get_focused, CPP:633-703 ----
+    double s6[6]; int j6[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
+    double nn_min = __builtin_inf();
+    if (active) {
+        // sorted insert; j arrives in ascending order, so an equal distance already listed stays in front (ties keep
+        // the lower index), and once the new entry is placed everything behind it moves down one place
+        auto consider = [&](int j, double s) {
+            double ks = s; int kj = j; bool placed = false;
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (placed || ks < s6[q]) { double ts = s6[q]; int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true; }
+        };
+        if (swarm) {
+            if constexpr (F32) {
+                const float pxf = L.px[i], pyf = L.py[i];
+                // Candidates (fp32 screen) go through a min/max insertion chain on single-precision keys (s32 with
+                // the low 10 bits replaced by the index) that keeps the 7 smallest.  The list is read off the keys
+                // when every neighbouring pair differs by at least two units of 1024 ulps and every listed key lies
+                // two units below T_sen; otherwise this agent redoes its list with exact double insertion.
+                unsigned K[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
+                for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                    unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
+                    if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));        // self removed CPP:677-681
+                    while (m) {
+                        const int j = j0 + __builtin_ctz(m); m &= m - 1;
+                        const float rx = L.px[j] - pxf, ry = L.py[j] - pyf;
+                        unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~1023u) | (unsigned)j;
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                    }
+                }
+                const unsigned tlo = (__float_as_uint(P.Tsen_f) >> 10) - 2u;
+                bool redo = false;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const bool there = K[q] != 0xFFFFFFFFu;
+                    const unsigned u = K[q] >> 10;
+                    redo |= there && (u >= tlo || (K[q + 1] >> 10) - u < 2u);
+                    j6[q] = there ? (int)(K[q] & 1023u) : -1;
+                }
+                if (redo) {                                                     // rare
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) j6[q] = -1;
+                    for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                        unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
+                        if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
+                        while (m) {                                             // ascending j: ties keep the lower index
+                            const int j = j0 + __ffs(m) - 1; m &= m - 1;
+                            const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                            const double s = dx * dx + dy * dy;                 // CPP:641
+                            if (s < P.T_sen) consider(j, s);                    // CPP:663
+                        }
+                    }
+                }
+                if (P.want_stats) {                                             // nearest other agent (WRAP:81-99)
+                    double s0 = 0.0;
+                    if (j6[0] >= 0) { const double dx = (double)L.px[j6[0]] - px, dy = (double)L.py[j6[0]] - py; s0 = dx * dx + dy * dy; }
+                    if (s0 > 0.0) nn_min = s0;
+                    else
+                        for (int j = 0; j < n_a; ++j) {
+                            const double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py, su = rx * rx + ry * ry;
+                            if (su != 0 && su < nn_min) nn_min = su;
+                        }
+                }
+            }
+        } else if (F32 && !P.periodic) {
+            const float pxf = (float)L.px[i], pyf = (float)L.py[i];
+            float nn32 = __builtin_inff(); int nnj = -1;
+            for (int j = 0; j < n_a; ++j) {
+                const float rx = (float)L.px[j] - pxf, ry = (float)L.py[j] - pyf;
+                const float s32 = __builtin_fmaf(ry, ry, rx * rx);
+                if (P.want_stats && s32 < nn32 && s32 > 0.0f) { nn32 = s32; nnj = j; }
+                if (j != i && s32 < P.Tsen_hi_f) {                       // candidates only: exact evaluation
+                    const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                    const double s = dx * dx + dy * dy;                  // CPP:641
+                    if (s < P.T_sen) consider(j, s);                     // CPP:663, self removed CPP:677-681
+                }
+            }
+            if (nnj >= 0) { const double dx = (double)L.px[nnj] - px, dy = (double)L.py[nnj] - py; nn_min = dx * dx + dy * dy; }
+        } else {
+            for (int j = 0; j < n_a; ++j) {
+                double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py; // CPP:84
+                if (P.want_stats) { double su = rx * rx + ry * ry; if (su != 0 && su < nn_min) nn_min = su; }
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
+                const double s = rx * rx + ry * ry;                          // CPP:641
+                if (j != i && s < P.T_sen) consider(j, s);
+            }
+        }
+        // agent block, column-major flatten of rows [pos_x,pos_y,vel_x,vel_y] (CPP:108-131)
+        int r0 = 0;
+        if (P.con_self) {
+            ocol[0] = (S)px; ocol[(size_t)n_a] = (S)py; ocol[(size_t)2 * n_a] = (S)vx; ocol[(size_t)3 * n_a] = (S)vy;
+            r0 = 4;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            int j = j6[q];
+            double rx = 0, ry = 0, wx = 0, wy = 0;
+            if (j >= 0) {
+                rx = (double)L.px[j] - px; ry = (double)L.py[j] - py;
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (P.cartesian) { wx = (double)L.vx[j] - vx; wy = (double)L.vy[j] - vy; }   // CPP:86
+                else {                                                                       // CPP:88
+                    wx = (double)heading_g[j] - (double)heading_g[i];
+                    wy = (double)heading_g[n_a + j] - (double)heading_g[n_a + i];
+                }
+            }
+            nbr_g[((size_t)e * n_a + i) * 6 + q] = j;                    // CPP:103-105
+            size_t r = (size_t)(r0 + 4 * q) * n_a;
+            ocol[r] = (S)rx; ocol[r + n_a] = (S)ry; ocol[r + 2 * (size_t)n_a] = (S)wx; ocol[r + 3 * (size_t)n_a] = (S)wy;
+        }
+    }
+
+    STAMP(4);
+    // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
+    for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
+    __syncthreads();
+    double smin = 0.0; int imin = 0;
+    if (active) {
+        bool done = false;
+        if constexpr (F32) {
+            if (swarm) {
+                imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW,
+                                       L.wkey + (size_t)i * P.MW, L.occ, L.cov);
+                done = true;
+            } else
+                done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
+                                      reinterpret_cast<const float *>(L.gy), i, L.mask, L.occ, L.cov, imin);
+            if (done) { const double rx = (double)L.gx[imin] - px, ry = (double)L.gy[imin] - py; smin = rx * rx + ry * ry; }
+        }
+        if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
+    }
+    STAMP(5);
+    const double dmin = sqrt(smin);
+    const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
+    __syncthreads();
+
+    unsigned *mym = L.mask + (size_t)i * P.MW;
+    int n_before = 0, n_after = 0, n_occ = 0;
+    if (active) {
+        for (int w = 0; w < P.W; ++w) {
+            unsigned m = mym[w];
+            n_before += __popc(m);
+            if (in_flag) { n_occ += __popc(m & L.occ[w]); }              // CPP:155: only when inside the shape
+        }
+        n_after = n_before - n_occ;
+        inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;                 // CPP:139
+        nearest_g[(size_t)e * n_a + i] = imin;
+
+        // target block (CPP:141-142, 896-901)
+        double t0, t1, t2, t3;
+        if (in_flag) { t0 = px - px; t1 = py - py; t2 = vx - vx; t3 = vy - vy; }
+        else { t0 = (double)L.gx[imin] - px; t1 = (double)L.gy[imin] - py; t2 = 0.0 - vx; t3 = 0.0 - vy; }
+        const int tb = P.cartesian ? P.obs_dim - (2 + P.n_obs) * 2 : P.obs_dim - 6;   // CPP:304, 317
+        ocol[(size_t)(tb + 0) * n_a] = (S)t0; ocol[(size_t)(tb + 1) * n_a] = (S)t1;
+        ocol[(size_t)(tb + 2) * n_a] = (S)t2; ocol[(size_t)(tb + 3) * n_a] = (S)t3;
+        if (!P.cartesian) {                                              // CPP:322-324
+            ocol[(size_t)(tb + 4) * n_a] = heading_g[i]; ocol[(size_t)(tb + 5) * n_a] = heading_g[n_a + i];
+        }
+
+        // occupied list = sensed_before \ sensed_after (CPP:215-238)
+        if (occup_g) {
+            int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
+            BitIter it; it.init(mym, P.W, L.occ, false);
+            emit_list(it, n_occ, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+        }
+    }
+
+    STAMP(6);
+    // ---- sensed list (CPP:243-296) and exploration reward terms (CPP:499-557) ----
+    // psi = rho_cos_dec(z, 0, d_sen), CPP:1017-1025
+    auto psi_exact = [&](double gx, double gy) {
+        const double z = sqrt(gx * gx + gy * gy);                        // CPP:524
+        if (z < 0.0 * P.d_sen) return 1.0;
+        else if (z < P.d_sen) return (1.0 / 2.0) * (1.0 + cos(ASM_PI * (z / P.d_sen - 0.0) / (1.0 - 0.0)));
+        return 0.0;
+    };
+    double num0 = 0.0, num1 = 0.0, den = 0.0;
+    bool uniform = false, uniform_known = false;
+    if (active) {
+        BitIter it; it.init(mym, P.W, in_flag ? L.occ : nullptr, true);
+        int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * P.n_obs : nullptr;
+        const int gb = P.obs_dim - P.n_obs * 2;
+        const bool cart = P.cartesian != 0;
+        const bool rew_on = in_flag && P.want_reward;
+        if constexpr (F32) {
+            // values: fl32(cell - p) is the correctly rounded difference either way; reward
+            // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within 2e-4 of 0.05
+            const float pxf = (float)L.px[i], pyf = (float)L.py[i];
+            float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+            emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+                float gx = 0.f, gy = 0.f;
+                if (cell >= 0) {
+                    gx = (float)L.gx[cell] - pxf; gy = (float)L.gy[cell] - pyf;          // CPP:285-286
+                    if (rew_on) {
+                        const float z = __builtin_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float psi = 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f);   // cos(pi z / d_sen)
+                        fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
+                    }
+                }
+                ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy;
+                if (sdst) sdst[k] = cell;
+            });
+            if (rew_on && n_after > 0 && fden > 0.f) {
+                const float v0 = fn0 / fden, v1 = fn1 / fden;
+                const float vn = __builtin_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                if (__builtin_fabsf(vn - 0.05f) > 2e-4f) { uniform = vn < 0.05f; uniform_known = true; }
+            }
+            if (rew_on && n_after > 0 && !uniform_known) {               // borderline: the exact sums
+                BitIter it2; it2.init(mym, P.W, L.occ, true);
+                emit_list(it2, n_after, P.n_obs, [&](int, int cell) {
+                    if (cell >= 0) {
+                        const double gx = (double)L.gx[cell] - px, gy = (double)L.gy[cell] - py;
+                        const double psi = psi_exact(gx, gy);
+                        num0 += psi * gx; num1 += psi * gy; den += psi;
+                    }
+                });
+            }
+        } else {
+            emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+                double gx = 0.0, gy = 0.0;
+                if (cell >= 0) {
+                    gx = (double)L.gx[cell] - px; gy = (double)L.gy[cell] - py;          // CPP:285-286, 515-516
+                    if (rew_on) { const double psi = psi_exact(gx, gy); num0 += psi * gx; num1 += psi * gy; den += psi; }  // CPP:537-539
+                }
+                if (cart) { ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy; }
+                if (sdst) sdst[k] = cell;
+            });
+        }
+    }
+
+    STAMP(7);
+    // ---- reward: CPP:457-564 ----
+    double reward = 0.0;
+    if (active && P.want_reward) {
+        bool collision = false;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {                                    // CPP:464-496
+            int j = j6[q];
+            if (j >= 0) {
+                double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py;
+                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (rx * rx + ry * ry < P.T_ravoid) collision = true;    // CPP:487 r_avoid > norm
+            }
+        }
+        if (in_flag && n_after > 0 && !uniform_known) {
+            if (den == 0) den = 1E-8;                                    // CPP:542-544
+            double v0 = 1.0 * num0 / den, v1 = 1.0 * num1 / den;         // CPP:547-548
+            uniform = v0 * v0 + v1 * v1 < P.T_v005;                      // CPP:550-552
+        }
+        if (in_flag && !collision && uniform) reward += 1.0;             // CPP:559-561
+        if (rew_g) rew_g[(size_t)e * n_a + i] = (S)reward;
+    }
+
+    STAMP(8);
+    // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
+    if (P.want_stats) {
+        __syncthreads();                                                 // masks no longer needed
+        double *scr = reinterpret_cast<double *>(L.mask);                // 4 doubles per agent (MW >= 8 words)
+        if (active) {
+            scr[(size_t)i * 4 + 0] = reward; scr[(size_t)i * 4 + 1] = sqrt(nn_min);
+            scr[(size_t)i * 4 + 2] = dmin;   scr[(size_t)i * 4 + 3] = in_flag ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (swarm) {
+            // whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials
+            const int wave = i >> 6, nw = P.SL >> 6;
+            double *part = scr + (size_t)4 * P.SL;                           // [nw][8] behind the per-agent values
+            double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0,
+                           active ? sqrt(nn_min) : 0.0, active ? sqrt(nn_min) : __builtin_inf(),
+                           active ? sqrt(nn_min) : -__builtin_inf(), 0.0};
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
+                v[3] += __shfl_xor(v[3], m, 64);
+                v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
+            }
+            if ((i & 63) == 0) for (int q = 0; q < 6; ++q) part[wave * 8 + q] = v[q];
+            __syncthreads();
+            double ms = 0;
+            for (int w = 0; w < nw; ++w) ms += part[w * 8 + 3];
+            const double mean = ms / n_a, dv = active ? sqrt(nn_min) - mean : 0.0;
+            double sq = dv * dv;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+            if ((i & 63) == 0) part[wave * 8 + 6] = sq;
+            __syncthreads();
+            if (i == 0 && e < P.E) {
+                double rs = 0, ds = 0, inn = 0, var = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+                for (int w = 0; w < nw; ++w) {
+                    rs += part[w * 8]; ds += part[w * 8 + 1]; inn += part[w * 8 + 2]; var += part[w * 8 + 6];
+                    lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
+                }
+                var /= n_a;
+                int covered = 0;
+                for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
+                double *st = stats_g + (size_t)e * 8;
+                st[0] += rs; st[1] += rs; st[2] += (double)covered / P.n_g_e;   // rewards are 0 or 1
+                st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
+                st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+            }
+        } else if (i == 0 && e < P.E) {
+            double rs = 0, rq = 0, ds = 0, inn = 0, ms = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+            for (int a = 0; a < n_a; ++a) {
+                double r = scr[(size_t)a * 4], m = scr[(size_t)a * 4 + 1];
+                rs += r; rq += r * r; ds += scr[(size_t)a * 4 + 2]; inn += scr[(size_t)a * 4 + 3];
+                ms += m; lo = fmin(lo, m); hi = fmax(hi, m);
+            }
+            double mean = ms / n_a, var = 0;
+            for (int a = 0; a < n_a; ++a) { double d = scr[(size_t)a * 4 + 1] - mean; var += d * d; }
+            var /= n_a;
+            int covered = 0;
+            for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
+            double *st = stats_g + (size_t)e * 8;
+            st[0] += rs; st[1] += rq; st[2] += (double)covered / P.n_g_e;
+            st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
+            st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+        }
+    }
+    STAMP(9);
+}
+
+// Loads the environment's grid (padded with far-away cells) and state into LDS.
+template <typename S>
+__device__ __forceinline__ void load_env(const DevParams &P, const EnvLds<S> &L, bool env_ok, bool active, int e,
+                                         int i, int n_g, const S *p_g, const S *dp_g, const S *grid_g)
+{
+    for (int c = i; c < P.NGP; c += P.SL) {
+        S x = (S)1e30, y = (S)1e30;
+        if (env_ok && c < n_g) {
+            x = grid_g[(size_t)e * 2 * P.n_g_max + c];
+            y = grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c];
+        }
+        L.gx[c] = x; L.gy[c] = y;
+    }
+    if (active) {
+        const size_t b = (size_t)e * 2 * P.n_a;
+        L.px[i] = p_g[b + i]; L.py[i] = p_g[b + P.n_a + i];
+        L.vx[i] = dp_g[b + i]; L.vy[i] = dp_g[b + P.n_a + i];
+    } else {                                                                 // unused slots: far away, so the chunked
+        L.px[i] = (S)1e30; L.py[i] = (S)1e30; L.vx[i] = (S)0; L.vy[i] = (S)0;   // pair screens never select them
+    }
+}
+
+// ---------------------------------------------------------------------------------
+template <typename S>
+__global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *heading_g, const S *grid_g,
+                          const int *ng_g, const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g,
+                          S *obs_g, S *rew_g, int *sensed_g, int *occup_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    const int n_g = env_ok ? ng_g[e] : 0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
+    __syncthreads();
+    DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0;
+    observe<S>(Q, L, active, e, i, l_cell, heading_g, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+               nullptr, 0);
+}
+
+// ENV:482-661: forces + prior on the old state, integration, observation + reward.
+template <typename S>
+__global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S *grid_g, const int *ng_g,
+                       const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
+                       S *prior_g, int *sensed_g, int *occup_g, double *stats_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    STAMP(0);
+    const int n_g = env_ok ? ng_g[e] : 0;
+    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
+    __syncthreads();
+    STAMP(1);
+
+    double npx = 0, npy = 0, nvx = 0, nvy = 0;
+    int contacts = 0;
+    if (active) {
+        const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
+        // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
+        double fx = 0.0, fy = 0.0;
+        if (sizeof(S) == 4 && !P.periodic && P.SL >= 64) {                       // large swarm: 32 agents per screen
+            if constexpr (sizeof(S) == 4) {
+                const float pxf = L.px[i], pyf = L.py[i];
+                for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                    unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tcontact_hi_f);
+                    if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
+                    while (m) {                                                  // ascending k, CPP:740-820
+                        const int k = j0 + __ffs(m) - 1; m &= m - 1;
+                        const double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;
+                        const double s = dx * dx + dy * dy;
+                        if (s < P.T_contact) {
+                            const double d = sqrt(s), gap = fabs(d - P.sizes2);
+                            fx += 1.0 * gap * P.k_ball * (-(dx / d));
+                            fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                            if (k > i) ++contacts;
+                        }
+                    }
+                }
+            }
+        } else
+        for (int k = 0; k < n_a; ++k) {
+            if (k == i) continue;
+            if (sizeof(S) == 4) {                                                // fp32 screen: certain misses
+                const float fx32 = (float)L.px[k] - (float)L.px[i], fy32 = (float)L.py[k] - (float)L.py[i];
+                if (!(__builtin_fmaf(fy32, fy32, fx32 * fx32) < P.Tcontact_hi_f) && !(P.want_stats && P.periodic && i == 0)) continue;
+            }
+            double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;         // CPP:782-785 (delta = p_k - p_i)
+            double s = dx * dx + dy * dy;                                        // ENV:444 (no wrap for rows >= 1)
+            if (s < P.T_contact) {                                               // ENV:445-446 d - sizes < 0
+                double d = sqrt(s);
+                double gap = fabs(d - P.sizes2);                                 // ENV:447
+                fx += 1.0 * gap * P.k_ball * (-(dx / d));                        // CPP:790-793
+                fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                if (k > i) ++contacts;
+            } else if (P.want_stats && P.periodic && i == 0) {
+                // ENV:442-443: only agent 0's row of the distance matrix is wrapped; it is
+                // never read by the force loop but is counted by WRAP:131-145.
+                double wx = dx, wy = dy; wrap_rel(wx, wy, P.half_w, P.half_h);
+                if (wx * wx + wy * wy < P.T_contact) ++contacts;
+            }
+        }
+        // ---- walls: CPP:822-860, ENV:510-513 ----
+        double wfx = 0.0, wfy = 0.0, dfx = 0.0, dfy = 0.0;
+        if (!P.periodic) {
+            const double r = P.size_a;
+            double d0 = px - r - (-P.half_w);                                    // CPP:841 (boundary_pos[0] = -half_w)
+            double d1 = P.half_h - (py + r);                                     // CPP:842
+            double d2 = P.half_w - (px + r);                                     // CPP:843
+            double d3 = py - r - (-P.half_h);                                    // CPP:844
+            const bool c0 = d0 < 0, c1 = d1 < 0, c2 = d2 < 0, c3 = d3 < 0;       // CPP:849
+            const double a0 = c0 ? fabs(d0) : 0.0, a1 = c1 ? fabs(d1) : 0.0;
+            const double a2 = c2 ? fabs(d2) : 0.0, a3 = c3 ? fabs(d3) : 0.0;
+            wfx = (a0 - a2) * P.k_wall;                                          // ENV:512 row 0: [1,0,-1,0]
+            wfy = (-a1 + a3) * P.k_wall;                                         //         row 1: [0,-1,0,1]
+            dfx = (-(c0 ? vx : 0.0) + -(c2 ? vx : 0.0)) * P.c_wall;              // ENV:513 row 0: [-1,0,-1,0]
+            dfy = (-(c1 ? vy : 0.0) + -(c3 ? vy : 0.0)) * P.c_wall;              //         row 1: [0,-1,0,-1]
+        }
+        // ---- prior on the OLD state with the PREVIOUS neighbour list: ENV:600-619 ----
+        if (P.prior && prior_g) {
+            int nb[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+            double tx, ty;
+            bool inf; int near;
+            if (P.recompute) {
+                double smin; cell_pass<S, false>(P, true, px, py, L.gx, L.gy, i, nullptr, nullptr, nullptr, smin, near);
+                inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
+            } else {
+                inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
+            }
+            if (inf) { tx = px; ty = py; } else { tx = (double)L.gx[near]; ty = (double)L.gy[near]; }  // CPP:896-901
+            double f0, f1;
+            prior_policy<S>(P, px, py, vx, vy, tx, ty, nb, L.px, L.py, L.vx, L.vy, f0, f1);
+            prior_g[(size_t)e * 2 * n_a + i] = (S)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (S)f1;
+        }
+        // ---- integration: ENV:626-647 ----
+        const float sens = (float)P.sens;
+        double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);             // ENV:627,633 (1 * float32)
+        double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        double Fx = ux + fx, Fy = uy + fy;
+        if (!P.periodic) { Fx = Fx + wfx + dfx; Fy = Fy + wfy + dfy; }           // ENV:633
+        nvx = vx + (Fx / P.mass) * P.dt; nvy = vy + (Fy / P.mass) * P.dt;        // ENV:638-641
+        nvx = fmin(fmax(nvx, -P.vel_max), P.vel_max);                            // ENV:642
+        nvy = fmin(fmax(nvy, -P.vel_max), P.vel_max);
+        npx = px + nvx * P.dt; npy = py + nvy * P.dt;                            // ENV:645
+        if (P.periodic) {                                                        // ENV:646-647, 778-781
+            if (npx < -P.half_w) npx += 2 * P.half_w;
+            if (npx > P.half_w) npx -= 2 * P.half_w;
+            if (npy < -P.half_h) npy += 2 * P.half_h;
+            if (npy > P.half_h) npy -= 2 * P.half_h;
+        }
+    }
+    STAMP(2);
+    // contact pairs of the environment (upper triangle, WRAP:141-145)
+    int contact_pairs = 0;
+    if (P.want_stats) {
+        __syncthreads();
+        int *cnt = reinterpret_cast<int *>(L.occ);
+        if (i == 0) cnt[0] = 0;
+        __syncthreads();
+        if (active && contacts) atomicAdd(&cnt[0], contacts);
+        __syncthreads();
+        contact_pairs = cnt[0];
+    }
+    __syncthreads();                                                             // all reads of the old state done
+    if (active) {
+        const S a = (S)npx, b = (S)npy, c = (S)nvx, d = (S)nvy;
+        L.px[i] = a; L.py[i] = b; L.vx[i] = c; L.vy[i] = d;
+        const size_t o = (size_t)e * 2 * n_a;
+        p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = d;
+    }
+    __syncthreads();
+    STAMP(3);
+    DevParams Q = P; Q.n_g_e = n_g;
+    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+               stats_g, contact_pairs);
+}
+
+// ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset
+// x/y, coin, 2*n_a positions, 2 centre, 2*n_a velocities), then the observation.
+template <typename S>
+__global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
+                        const double *shape_grids, const int *shape_off, const int *shape_ng,
+                        const double *shape_lcell, int *shape_id_g, S *p_g, S *dp_g, S *grid_g, int *ng_g,
+                        double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, int *sensed_g,
+                        int *occup_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
+    const int n_a = P.n_a;
+    EnvLds<S> L = carve<S>(smem, P, es);
+    const uint64_t env = (uint64_t)(env0 + e);
+    int n_g = 0; double l_cell = 1.0;
+    if (env_ok) {
+        uint32_t d = 0;
+        const int s = (int)(((uint64_t)draw_u32(seed, env, episode, 0u, d++) * (uint64_t)n_shapes) >> 32);  // ENV:155
+        n_g = shape_ng[s]; l_cell = shape_lcell[s];
+        const double ang = ASM_PI * draw_uniform(seed, env, episode, d++, -1.0, 1.0);                      // ENV:170
+        d += 2;                                                                                            // ENV:177
+        const double ox = draw_uniform(seed, env, episode, d++, -P.half_w + 1, P.half_w - 1);              // ENV:179
+        const double oy = draw_uniform(seed, env, episode, d++, -P.half_h + 1, P.half_h - 1);              // ENV:180
+        const double ca = cos(ang), sa = sin(ang);
+        const double *g = shape_grids + 2 * (size_t)shape_off[s];
+        for (int c = i; c < P.NGP; c += P.SL) {
+            S x = (S)1e30, y = (S)1e30;
+            if (c < n_g) {                                                                                 // ENV:172-173,182
+                double gx = g[2 * c], gy = g[2 * c + 1];
+                x = (S)((ca * gx + sa * gy) + ox); y = (S)((-sa * gx + ca * gy) + oy);
+            }
+            L.gx[c] = x; L.gy[c] = y;
+            if (c < P.n_g_max) {
+                grid_g[(size_t)e * 2 * P.n_g_max + c] = c < n_g ? x : (S)0;
+                grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c] = c < n_g ? y : (S)0;
+            }
+        }
+        const double coin = draw_uniform(seed, env, episode, d++, -1.0, 1.0);                              // ENV:197
+        const uint32_t dpos = d, dctr = d + 2u * (uint32_t)n_a, dvel = dctr + 2u;
+        if (i == 0) { shape_id_g[e] = s; ng_g[e] = n_g; lcell_g[e] = l_cell; }
+        if (active) {
+            double x, y;
+            if (coin > 0) {                                                                                // ENV:198-200
+                x = draw_uniform(seed, env, episode, dpos + (uint32_t)i, -P.half_w, P.half_w);
+                y = draw_uniform(seed, env, episode, dpos + (uint32_t)(n_a + i), -P.half_h, P.half_h);
+            } else {                                                                                       // ENV:202-203
+                const double cx = draw_uniform(seed, env, episode, dctr, -P.half_w + 1, P.half_w - 1);
+                const double cy = draw_uniform(seed, env, episode, dctr + 1u, -P.half_h + 1, P.half_h - 1);
+                x = draw_uniform(seed, env, episode, dpos + (uint32_t)i, -1.0, 1.0) + cx;
+                y = draw_uniform(seed, env, episode, dpos + (uint32_t)(n_a + i), -1.0, 1.0) + cy;
+            }
+            const double u = draw_uniform(seed, env, episode, dvel + (uint32_t)i, -0.5, 0.5);              // ENV:210
+            const double v = draw_uniform(seed, env, episode, dvel + (uint32_t)(n_a + i), -0.5, 0.5);
+            const S a = (S)x, b = (S)y, c = (S)u, dd = (S)v;
+            L.px[i] = a; L.py[i] = b; L.vx[i] = c; L.vy[i] = dd;
+            const size_t o = (size_t)e * 2 * n_a;
+            p_g[o + i] = a; p_g[o + n_a + i] = b; dp_g[o + i] = c; dp_g[o + n_a + i] = dd;
+        } else {
+            L.px[i] = (S)1e30; L.py[i] = (S)1e30; L.vx[i] = (S)0; L.vy[i] = (S)0;
+        }
+    } else {
+        for (int c = i; c < P.NGP; c += P.SL) { L.gx[c] = (S)1e30; L.gy[c] = (S)1e30; }
+    }
+    if (P.state_only) return;                                       // the caller observes the new state with k_step_fast
+    __syncthreads();
+    DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0; Q.want_reward = 0;
+    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, nullptr, sensed_g, occup_g,
+               nullptr, 0);
+}
+
