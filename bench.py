@@ -106,6 +106,7 @@ def main():
                     help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-indices", action="store_true", help="also materialise sensed/occupied index lists")
+    ap.add_argument("--periodic", action="store_true", help="periodic arena instead of walls (is_boundary=False, ENV:97-101)")
     ap.add_argument("--regime", choices=["random", "packed"], default="random",
                     help="random: the reference's reset (ENV:197-210), most agents outside the shape; packed: every "
                          "agent starts on a cell of its shape (the converged regime: full sensing, occupancy filter, sub-sampling)")
@@ -147,7 +148,7 @@ def main():
     # The rank's environments as S shards on S HIP streams (contiguous global ids: the same environments
     # as one batch of E); S launches are in flight, one shard's ramp and tail under the other's steady state.
     shards = StreamShards(E, n_a, parts=S, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0],
-                          keep_indices=args.keep_indices)
+                          keep_indices=args.keep_indices, is_boundary=not args.periodic)
 
     def reset_one(k, env, episode=None):
         env.reset(episode=episode)
@@ -259,7 +260,7 @@ def main():
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{E} parallel assembly envs x {n_a} agents per GPU, random U(-1,1) actions "
-                                   f"(configs[1] of BASELINE.json), 7 reference shapes, walls on, llm_rl prior on"
+                                   f"(configs[1] of BASELINE.json), 7 reference shapes, {'periodic arena' if args.periodic else 'walls on'}, llm_rl prior on"
                                    + (", agents started inside their shapes" if args.regime == "packed" else ""),
                        "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
                        "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,

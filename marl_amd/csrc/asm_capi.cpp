@@ -116,11 +116,12 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     P.capp = P.n_obs + (P.n_obs & 1);                               // even, and an odd number of 32-bit words per
     if (((P.capp / 2) & 1) == 0) P.capp += 2;                       // agent: no LDS bank conflicts across lanes
     P.fast_T = 0;
-    if (state_bytes == 4 && prm->n_a <= 32 && !P.periodic && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
+    if (state_bytes == 4 && prm->n_a <= 32 && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
         const int blocks = (E + 1) / 2;
         (void)blocks;
         int T = 4;                                                   // fastest measured schedule at every batch size from 2048 to 32768 environments
         if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
+        if (P.periodic && T != 4) T = 0;                            // the periodic arena is built for 4 waves only
         if (T == 1 || T == 2 || T == 4) {
             // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on; masks; occupancy;
             // partials; flags; reward partials; slot lists (+ one emission round of padding) aliased with the word keys

@@ -89,13 +89,13 @@ int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading
     return 0;
 }
 
-template <int T>
+template <int T, bool PER>
 static int launch_step_fast_t(const DevParams &P, float *p, float *dp, const float *act, const float *grid,
                               const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs,
                               float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
 {
-    if (int rc = set_lds(k_step_fast<T>, P.fast_lds_bytes)) return rc;
-    hipLaunchKernelGGL(k_step_fast<T>, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, p, dp, act, grid, n_g,
+    if (int rc = set_lds(k_step_fast<T, PER>, P.fast_lds_bytes)) return rc;
+    hipLaunchKernelGGL((k_step_fast<T, PER>), dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, p, dp, act, grid, n_g,
                        l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
     LAUNCH_CHECK();
     return 0;
@@ -109,10 +109,12 @@ int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, 
     { const char *x = std::getenv("MARL_AMD_DBG_EXIT"); const int v = x ? std::atoi(x) : 0;
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
 #endif
+    if (P.periodic)                                                 // the host offers the periodic arena at T = 4 only
+        return launch_step_fast_t<4, true>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
     switch (P.fast_T) {
-    case 1: return launch_step_fast_t<1>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
-    case 2: return launch_step_fast_t<2>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
-    default: return launch_step_fast_t<4>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    case 1: return launch_step_fast_t<1, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    case 2: return launch_step_fast_t<2, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    default: return launch_step_fast_t<4, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
     }
 }
 

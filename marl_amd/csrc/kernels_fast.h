@@ -16,6 +16,16 @@
 //   * pair loops (contacts, k-NN) screen all 32 candidates in fp32 into a bit mask and run the
 //     exact double evaluation only on the set bits.
 // T is chosen by the host so that a launch has enough waves to fill the chip.
+// fl32 |wrap(rx, ry)|^2 for the single-precision neighbour screen of a periodic arena (CPP:705-720 in float).  Where
+// the float and the double wrap could disagree (|r| within rounding of the half-width) the offset is about a
+// half-width long either way, far outside the sensing range, so the screen's verdict is the same.
+__device__ __forceinline__ float wrapped_s32(float rx, float ry, float hw, float hh)
+{
+    if (rx < -hw) rx += 2 * hw; else if (rx > hw) rx -= 2 * hw;
+    if (ry < -hh) ry += 2 * hh; else if (ry > hh) ry -= 2 * hh;
+    return __builtin_fmaf(ry, ry, rx * rx);
+}
+
 struct FastLds {
     float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
     float *g;                      // x rows of the two environments at [0, 2 NGP), their y rows ASM_GY_OFF floats further on
@@ -77,7 +87,7 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
-template <int T>
+template <int T, bool PER>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101)
 __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
@@ -188,6 +198,17 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 if (k > i) ++contacts;
             }
         }
+        if constexpr (PER) {
+            // ENV:442-443: only agent 0's row of the distance matrix is wrapped; the force loop never reads it, but
+            // the contact count (WRAP:131-145) does
+            if (P.want_stats && i == 0)
+                for (int k = 1; k < n_a; ++k) {
+                    double wx = (double)L.px[es * 32 + k] - px, wy = (double)L.py[es * 32 + k] - py;
+                    if (wx * wx + wy * wy < P.T_contact) continue;              // counted above
+                    wrap_rel(wx, wy, P.half_w, P.half_h);
+                    if (wx * wx + wy * wy < P.T_contact) ++contacts;
+                }
+        }
         // walls: CPP:822-860, ENV:510-513
         const double r = P.size_a;
         const double d0 = px - r - (-P.half_w), d1 = P.half_h - (py + r);       // CPP:841-842
@@ -201,12 +222,19 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const float sens = (float)P.sens;
         const double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);       // ENV:627,633
         const double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
-        const double Fx = ux + fx + wfx + dfx, Fy = uy + fy + wfy + dfy;         // ENV:633
+        const double Fx = PER ? ux + fx : ux + fx + wfx + dfx, Fy = PER ? uy + fy : uy + fy + wfy + dfy;   // ENV:633
         double ax = Fx, ay = Fy;
         if (P.mass != 1.0) { ax = Fx / P.mass; ay = Fy / P.mass; }               // ENV:638 (x / 1 == x)
         double v0 = vx + ax * P.dt, v1 = vy + ay * P.dt;                         // ENV:641
         v0 = fmin(fmax(v0, -P.vel_max), P.vel_max); v1 = fmin(fmax(v1, -P.vel_max), P.vel_max);   // ENV:642
-        npx = (float)(px + v0 * P.dt); npy = (float)(py + v1 * P.dt);            // ENV:645
+        double qx = px + v0 * P.dt, qy = py + v1 * P.dt;                         // ENV:645
+        if constexpr (PER) {                                                     // ENV:646-647, 778-781
+            if (qx < -P.half_w) qx += 2 * P.half_w;
+            if (qx > P.half_w) qx -= 2 * P.half_w;
+            if (qy < -P.half_h) qy += 2 * P.half_h;
+            if (qy > P.half_h) qy -= 2 * P.half_h;
+        }
+        npx = (float)qx; npy = (float)qy;
         nvx = (float)v0; nvy = (float)v1;
     }
     if (sub == SUB_PRIOR && active && P.prior && prior_g) {         // ENV:600-619: old state, previous neighbour list
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #pragma unroll
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
     double nn_min = __builtin_inf();
+    [[maybe_unused]] const float hw32 = (float)P.half_w, hh32 = (float)P.half_h;
     if (sub == 0 && active && xat != 13) {
         // k nearest neighbours inside d_sen (_get_focused, CPP:633-703): fp32 screen, exact on candidates
         unsigned cand = 0, n1 = 0xFFFFFFFFu, n2 = 0xFFFFFFFFu;
@@ -267,7 +296,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             for (int r = 0; r < 4; ++r) {
                 const float rx = xs[r] - pxf, ry = ys[r] - pyf;
                 const float s = __builtin_fmaf(ry, ry, rx * rx);
-                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(s - P.Tsen_hi_f), 31);
+                // sensing uses the wrapped offset in a periodic arena (CPP:93-95), the uniformity statistic the plain one
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint((PER ? wrapped_s32(rx, ry, hw32, hh32) : s) - P.Tsen_hi_f), 31);
                 const unsigned key = (__float_as_uint(s) & ~31u) | (unsigned)(j4 + r);   // two smallest: self (0)
                 n2 = umed3(n1, n2, key); n1 = n1 < key ? n1 : key;                        // and the nearest neighbour
             }
@@ -286,7 +316,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         while (cand) {
             const int j = __builtin_ctz(cand); cand &= cand - 1;
             const float rx = L.px[es * 32 + j] - pxf, ry = L.py[es * 32 + j] - pyf;
-            unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~31u) | (unsigned)j;
+            unsigned x = (__float_as_uint(PER ? wrapped_s32(rx, ry, hw32, hh32) : __builtin_fmaf(ry, ry, rx * rx)) & ~31u) | (unsigned)j;
 #pragma unroll
             for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
         }
@@ -306,7 +336,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 cand = cand_all;
                 while (cand) {                                      // ascending j: ties keep the lower index
                     const int j = __ffs(cand) - 1; cand &= cand - 1;
-                    const double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+                    double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+                    if constexpr (PER) wrap_rel(dx, dy, P.half_w, P.half_h);   // CPP:93-95
                     const double s = dx * dx + dy * dy;             // CPP:641
                     if (s < P.T_sen) {                              // CPP:663
                         double ks = s; int kj = j; bool placed = false;     // once placed, the entries behind move down one place
@@ -333,6 +364,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             float rx = 0.f, ry = 0.f, wx = 0.f, wy = 0.f;
             if (j >= 0) {
                 rx = L.px[es * 32 + j] - pxf; ry = L.py[es * 32 + j] - pyf;
+                if constexpr (PER) {
+                    double dx = (double)L.px[es * 32 + j] - px, dy = (double)L.py[es * 32 + j] - py;
+                    wrap_rel(dx, dy, P.half_w, P.half_h);
+                    rx = (float)dx; ry = (float)dy;
+                }
                 wx = L.vx[es * 32 + j] - vxf; wy = L.vy[es * 32 + j] - vyf;      // CPP:86
             }
             nbr_g[((size_t)e * n_a + i) * 6 + q] = j;               // CPP:103-105
@@ -677,7 +713,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             for (int q = 0; q < 6; ++q) {                           // CPP:464-496
                 const int j = j6[q];
                 if (j >= 0) {
-                    const double rx = (double)L.px[es * 32 + j] - px, ry = (double)L.py[es * 32 + j] - py;
+                    double rx = (double)L.px[es * 32 + j] - px, ry = (double)L.py[es * 32 + j] - py;
+                    if constexpr (PER) wrap_rel(rx, ry, P.half_w, P.half_h);
                     if (rx * rx + ry * ry < P.T_ravoid) collision = true;   // CPP:487
                 }
             }
@@ -761,6 +798,14 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const uint4 q = L.part[l];
             dm = __hiloint2double((int)q.y, (int)q.x); nn = __hiloint2double((int)q.w, (int)q.z);
             cn = (int)((fin >> 16) & 0xFFu);
+        }
+        if (active && nn == 0.0) {                                  // an agent at this very position: WRAP:93-94 drops exact zeros
+            nn = __builtin_inf();
+#pragma nounroll
+            for (int j = 0; j < n_a; ++j) {
+                const double ex = (double)L.px[es * 32 + j] - px, ey = (double)L.py[es * 32 + j] - py, su = ex * ex + ey * ey;
+                if (su != 0 && su < nn) nn = su;
+            }
         }
         const double m = active ? sqrt(nn) : 0.0;
         int ci = cn + (i < W ? __popc(cov_e[i]) << 16 : 0);                                           // two small sums in one word

@@ -593,3 +593,34 @@ def test_without_prior_and_without_self_state(torch_cuda):
         act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
         teacher_forced_step(env, cfg, act, f"step {t}")
     assert env.step(torch.zeros(E, 2, n_a, device="cuda"))[4] is None
+
+
+def test_periodic_arena_kernels_agree(torch_cuda, monkeypatch):
+    """is_boundary = False (assembly.py:97-101): the multi-wave kernel's periodic instantiation against the generic
+    kernel, bit for bit, over an episode start in which agents cross the arena's edges (wrapped positions, wrapped
+    neighbour offsets, agent 0's wrapped contact row in the statistics)."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    E, n_a, steps = 64, 30, 40
+    outs = {}
+    for mode in ("4", "0"):
+        monkeypatch.setenv("MARL_AMD_FAST_T", mode)
+        env = BatchedAssemblyEnv(E, n_a, seed=91, is_boundary=False, keep_indices=True)
+        env.reset()
+        p = env.p.clone()
+        p[::2] = p[::2] * 0 + torch.tensor([2.3, -2.3], device="cuda")[None, :, None] + 0.15 * torch.randn(
+            E // 2, 2, n_a, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        p.clamp_(-2.4, 2.4)
+        env.p.copy_(p); env.dp.mul_(1.6).clamp_(-0.8, 0.8); env.observe()
+        rec = []
+        for t in range(steps):
+            obs, rew, _, _, prior = env.step(env.random_actions())
+            rec.append([x.clone() for x in (obs, rew, prior, env.p, env.dp, env.neighbor_index, env.in_flags, env.sensed_index)])
+        outs[mode] = (rec, env.stats.clone())
+        crossed = (env.p.abs() > 2.3).any().item()
+    for t in range(steps):
+        for k, (a, b) in enumerate(zip(outs["4"][0][t], outs["0"][0][t])):
+            assert torch.equal(a, b), f"step {t} output {k}"
+    assert torch.allclose(outs["4"][1], outs["0"][1], rtol=1e-5, atol=1e-9)
+    assert crossed
+    assert (outs["4"][0][-1][3].abs() <= 2.4).all()
