@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--keep-indices", action="store_true", help="also materialise sensed/occupied index lists")
+    ap.add_argument("--keep-indices", nargs="?", const="both", default=None, choices=["both", "sensed"],
+                    help="also materialise the sensed/occupied index lists (both) or the sensed list only")
     ap.add_argument("--periodic", action="store_true", help="periodic arena instead of walls (is_boundary=False, ENV:97-101)")
     ap.add_argument("--regime", choices=["random", "packed"], default="random",
                     help="random: the reference's reset (ENV:197-210), most agents outside the shape; packed: every "
@@ -148,7 +149,7 @@ def main():
     # The rank's environments as S shards on S HIP streams (contiguous global ids: the same environments
     # as one batch of E); S launches are in flight, one shard's ramp and tail under the other's steady state.
     shards = StreamShards(E, n_a, parts=S, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0],
-                          keep_indices=args.keep_indices, is_boundary=not args.periodic)
+                          keep_indices={None: False, "both": True, "sensed": "sensed"}[args.keep_indices], is_boundary=not args.periodic)
 
     def reset_one(k, env, episode=None):
         env.reset(episode=episode)

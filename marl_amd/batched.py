@@ -35,7 +35,7 @@ class BatchedAssemblyEnv:
     def __init__(self, num_envs: int, n_a: int = 30, *, device="cuda", seed: int = 226, env_id_offset: int = 0,
                  is_boundary: bool = True, is_con_self_state: bool = True, training_method: str = "llm_rl",
                  shapes=None, r_avoid: Optional[float] = None, d_sen: float = 0.4, n_g_max: Optional[int] = None,
-                 keep_indices: bool = False, keep_stats: bool = True, num_obs_grid_max: int = 80,
+                 keep_indices=False, keep_stats: bool = True, num_obs_grid_max: int = 80,
                  num_occupied_grid_max: int = 200):
         self.lib = _lib.load()
         self.E = int(num_envs)
@@ -84,8 +84,12 @@ class BatchedAssemblyEnv:
         self.reward = torch.zeros(E, 1, n, **f32)
         self.a_prior = torch.zeros(E, 2, n, **f32)
         self.done = torch.zeros(E, 1, n, dtype=torch.bool, device=dev)          # assembly.py:475-477
+        # keep_indices: True = both index lists of assembly.py:225-226, "sensed" = the sensed list only (what
+        # rule_actions needs; the occupied list costs far more to write), False = neither
+        if keep_indices not in (True, False, "sensed"):
+            raise ValueError('keep_indices is True, False or "sensed"')
         self.sensed_index = torch.full((E, n, int(num_obs_grid_max)), -1, **i32) if keep_indices else None
-        self.occupied_index = torch.full((E, n, int(num_occupied_grid_max)), -1, **i32) if keep_indices else None
+        self.occupied_index = torch.full((E, n, int(num_occupied_grid_max)), -1, **i32) if keep_indices is True else None
         self.stats = torch.zeros(E, 8, dtype=torch.float64, device=dev) if keep_stats else None
         # canonical shapes on the device (results.pkl 'grid_coords' layout, assembly.py:115)
         off = np.zeros(self.num_train_shape, np.int32)
@@ -182,7 +186,7 @@ class BatchedAssemblyEnv:
         """(E, 2, n_a) actions of the reference's 'rule' expert (assembly.py:525-596) for the current state, i.e.
         the state of the last reset()/step()/observe().  Needs keep_indices=True (the sensed lists)."""
         if self.sensed_index is None:
-            raise RuntimeError("rule_actions needs the sensed-index lists: construct with keep_indices=True")
+            raise RuntimeError('rule_actions needs the sensed-index lists: construct with keep_indices=True or "sensed"')
         if out is None:
             out = torch.empty(self.E, 2, self.n_a, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -33,7 +33,7 @@ struct FastLds {
     unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
     unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
     uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
-    unsigned *fin;                 // [64]         nearest cell | in_flag << 31
+    unsigned *fin;                 // [2][64]      nearest cell | contacts << 16 | in_flag << 31; then the list lengths (sensed-index output)
     float *rpart;                  // [T][3][64]   per-wave partial reward sums
     unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
 };
@@ -48,7 +48,7 @@ __device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevPara
     L.occ = L.mask + 64 * P.MW;
     L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
     L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
-    L.rpart = reinterpret_cast<float *>(L.fin + 64);
+    L.rpart = reinterpret_cast<float *>(L.fin + 128);
     L.sel = reinterpret_cast<unsigned short *>(L.rpart + 3 * 64 * T);
     return L;
 }
@@ -546,6 +546,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int wst = found ? __ffs(nzs) - 1 : 0;
     const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
+    if (sub == 0 && sensed_g) L.fin[64 + l] = (unsigned)n_out;      // for the row-wise copy of the lists in P6
     STAMP(16);
     [[maybe_unused]] int diag_it = 0;
     {
@@ -665,7 +666,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
     {
         const int gb = P.obs_dim - cap * 2;
-        int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * cap : nullptr;
         constexpr int RB = 10;                                      // slots per round: indices, coordinates, then math + stores
         if (active) {
             for (int kb = k0; kb < k1; kb += RB) {
@@ -684,13 +684,24 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #ifndef ASM_EXP_NOSTORE
                         ostore(gb + 2 * k, gx); ostore(gb + 2 * k + 1, gy);
 #endif
-                        if (sdst) sdst[k] = have[q] ? cell[q] : -1;
                         // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
                         const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
                         const float psi = have[q] ? __builtin_fmaf(0.5f, __builtin_amdgcn_cosf(z * P.inv2dsen_f), 0.5f) : 0.f;
                         fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
                     }
                 }
+            }
+        }
+        if (sensed_g) {
+            // sensed_index rows (CPP:341-345), copied from the LDS lists agent by agent so that the 64 lanes write
+            // 64 consecutive entries; the agents are dealt out to the waves
+            for (int a = sub; a < 64; a += T) {
+                const int ea = e0 + (a >> 5), ia = a & 31;
+                if (ea >= P.E || ia >= n_a) continue;
+                const int na = (int)L.fin[64 + a];
+                const unsigned short *src = L.sel + (size_t)a * P.capp;
+                int *dst = sensed_g + ((size_t)ea * n_a + ia) * cap;
+                for (int k = l; k < cap; k += 64) dst[k] = k < na ? (int)src[k] : -1;
             }
         }
         if (T > 1) { L.rpart[(sub * 3 + 0) * 64 + l] = fn0; L.rpart[(sub * 3 + 1) * 64 + l] = fn1; L.rpart[(sub * 3 + 2) * 64 + l] = fden; }
