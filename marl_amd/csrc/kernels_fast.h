@@ -87,7 +87,7 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
-template <int T, bool PER>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101)
+template <int T, bool PER, bool OCC>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); OCC: occupied_index is written
 __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
@@ -649,13 +649,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             }
         }
     }
-    if (sub == 0 && active && occup_g) {                            // occupied list (CPP:215-238), diagnostics only
-        int *dst = occup_g + ((size_t)e * n_a + i) * P.n_occ;
-        int n_occ_list = 0;
-        for (int w = 0; w < W; ++w) n_occ_list += __popc(mym[w] & occ_e[w]);
-        BitIter it; it.init(mym, W, occ_e, false);
-        emit_list(it, in_flag ? n_occ_list : 0, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
-    }
     STAMP(6);
     if (T > 1) __syncthreads();                                     // the lists are complete
     STAMP(15);
@@ -702,6 +695,40 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 const unsigned short *src = L.sel + (size_t)a * P.capp;
                 int *dst = sensed_g + ((size_t)ea * n_a + ia) * cap;
                 for (int k = l; k < cap; k += 64) dst[k] = k < na ? (int)src[k] : -1;
+            }
+        }
+        if constexpr (OCC) {
+            // occupied_index rows (CPP:215-238): the sensed cells some agent occupies, for agents inside the shape.  One
+            // agent at a time per wave; the 64 lanes test 64 cells (two mask words) per pass and the set ones are
+            // written in ascending order at ranks from a ballot prefix count; the rest of the row is -1.
+            for (int a = sub; a < 64; a += T) {
+                const int ea = e0 + (a >> 5), ia = a & 31;
+                if (ea >= P.E || ia >= n_a) continue;
+                const unsigned *ma = L.mask + (size_t)a * MW, *oc = L.occ + (a >> 5) * 2 * W;
+                int *dst = occup_g + ((size_t)ea * n_a + ia) * P.n_occ;
+                int cnt = 0;
+                if (L.fin[a] >> 31) {                                // CPP:155: only inside the shape
+                    int n = 0;
+                    for (int w = 0; w < W; ++w) n += __popc(ma[w] & oc[w]);
+                    if (n > P.n_occ) {                               // sub-sampled (CPP:224-229): rare, one lane walks the bits
+                        if (l == 0) {
+                            BitIter it; it.init(ma, W, oc, false);
+                            emit_list(it, n, P.n_occ, [&](int k, int cell) { dst[k] = cell; });
+                        }
+                        cnt = P.n_occ;
+                    } else {
+                        for (int w0 = 0; w0 < W; w0 += 2) {
+                            const int w = w0 + (l >> 5);
+                            const unsigned f = w < W ? ma[w] & oc[w] : 0u;
+                            const bool has = (f >> (l & 31)) & 1u;
+                            const unsigned long long bal = __ballot(has);
+                            const int rank = cnt + __popcll(bal & ((1ull << l) - 1ull));
+                            if (has) dst[rank] = w * 32 + (l & 31);
+                            cnt += __popcll(bal);
+                        }
+                    }
+                }
+                for (int k = cnt + l; k < P.n_occ; k += 64) dst[k] = -1;
             }
         }
         if (T > 1) { L.rpart[(sub * 3 + 0) * 64 + l] = fn0; L.rpart[(sub * 3 + 1) * 64 + l] = fn1; L.rpart[(sub * 3 + 2) * 64 + l] = fden; }
