@@ -94,7 +94,7 @@ static int launch_step_fast_t(const DevParams &P, float *p, float *dp, const flo
                               const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs,
                               float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
 {
-    // two instantiations: the occupied-index output is compiled in only where it is asked for
+    // three instantiations: the index-list outputs are compiled in only where they are asked for
     auto go = [&](auto kernel) {
         if (int rc = set_lds(kernel, P.fast_lds_bytes)) return rc;
         hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, p, dp, act, grid, n_g,
@@ -102,7 +102,7 @@ static int launch_step_fast_t(const DevParams &P, float *p, float *dp, const flo
         LAUNCH_CHECK();
         return 0;
     };
-    return occupied ? go(k_step_fast<T, PER, true>) : go(k_step_fast<T, PER, false>);
+    return occupied ? go(k_step_fast<T, PER, 2>) : sensed ? go(k_step_fast<T, PER, 1>) : go(k_step_fast<T, PER, 0>);
 }
 
 int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, const float *grid, const int *n_g,

@@ -87,7 +87,8 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
-template <int T, bool PER, bool OCC>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); OCC: occupied_index is written
+template <int T, bool PER, int IDX>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
+                                      // lists written (0 none, 1 sensed_index if given, 2 occupied_index too)
 __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int wst = found ? __ffs(nzs) - 1 : 0;
     const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
-    if (sub == 0 && sensed_g) L.fin[64 + l] = (unsigned)n_out;      // for the row-wise copy of the lists in P6
+    if (IDX >= 1 && sub == 0 && sensed_g) L.fin[64 + l] = (unsigned)n_out;      // for the row-wise copy of the lists in P6
     STAMP(16);
     [[maybe_unused]] int diag_it = 0;
     {
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 }
             }
         }
-        if (sensed_g) {
+        if (IDX >= 1 && sensed_g) {
             // sensed_index rows (CPP:341-345), copied from the LDS lists agent by agent so that the 64 lanes write
             // 64 consecutive entries; the agents are dealt out to the waves
             for (int a = sub; a < 64; a += T) {
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 for (int k = l; k < cap; k += 64) dst[k] = k < na ? (int)src[k] : -1;
             }
         }
-        if constexpr (OCC) {
+        if constexpr (IDX == 2) {
             // occupied_index rows (CPP:215-238): the sensed cells some agent occupies, for agents inside the shape.  One
             // agent at a time per wave; the 64 lanes test 64 cells (two mask words) per pass and the set ones are
             // written in ascending order at ranks from a ballot prefix count; the rest of the row is -1.
