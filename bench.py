@@ -151,6 +151,15 @@ def main():
     shards = StreamShards(E, n_a, parts=S, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0],
                           keep_indices={None: False, "both": True, "sensed": "sensed"}[args.keep_indices], is_boundary=not args.periodic)
 
+    def all_reduce_stats(v):
+        # gloo rehearsal only: the sum goes through the host (gloo's device-tensor path stalls when two ranks share a
+        # GPU that is busy on another stream); with RCCL the device vector is reduced in place, asynchronously
+        if world > 1 and backend != "nccl":
+            h = v.cpu()
+            dist.all_reduce(h)
+            return v.copy_(h)
+        return reduce_episode_stats(v)
+
     def reset_one(k, env, episode=None):
         env.reset(episode=episode)
         if args.regime == "packed":                           # agents onto random cells of their own shape, + 2 cm jitter
@@ -194,7 +203,9 @@ def main():
     phase = [0 if C else k * EPISODE_LENGTH // S for k in range(S)]
 
     def episode_end(k, env):                                # on shard k's stream
-        totals[k].add_(reduce_episode_stats(env.episode_stats()))   # RCCL SUM of 8 doubles over xGMI
+        mark(f"episode end, shard {k}")
+        totals[k].add_(all_reduce_stats(env.episode_stats()))       # RCCL SUM of 8 doubles over xGMI
+        mark(f"statistics reduced, shard {k}")
         reset_one(k, env)
 
     def run_steps(n, t0=0):
@@ -222,7 +233,7 @@ def main():
         shards.on_each(lambda k, env: reset_one(k, env, 0))
     run_steps(W)
     mark("warm-up steps done")
-    shards.on_each(lambda k, env: totals[k].add_(reduce_episode_stats(env.episode_stats())))
+    shards.on_each(lambda k, env: totals[k].add_(all_reduce_stats(env.episode_stats())))
     shards.synchronize()
     totals.zero_()
     mark("warm-up all-reduce done")
@@ -240,7 +251,7 @@ def main():
     wall = time.perf_counter() - t0
     # per stream: K launches back to back -> the average launch duration of the step kernel on that stream
     ev_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S
-    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax)
