@@ -80,7 +80,8 @@ def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 12.0):
         return time.perf_counter() - t0
 
     # calibrate on a small sample, then size the sample for ~target_seconds
-    E0, T0 = threads * 2, 20
+    E0, T0 = threads * 4, 40
+    run(threads, 5)                                          # thread start-up and first touches stay out of the calibration
     dt = run(E0, T0)
     per_env_step = dt * threads / (E0 * T0)                  # thread-seconds per env-step
     T = EPISODE_LENGTH
