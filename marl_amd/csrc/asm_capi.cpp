@@ -123,9 +123,9 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
         if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
         if (P.periodic && T != 4) T = 0;                            // the periodic arena is built for 4 waves only
         if (T == 1 || T == 2 || T == 4) {
-            // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on; masks; occupancy;
+            // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on, 64 own-position entries; masks; occupancy;
             // partials; flags; reward partials; slot lists (+ one emission round of padding) aliased with the word keys
-            const size_t bytes = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
+            const size_t bytes = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
                                  4 * 128 + 4 * 3 * 64 * (size_t)T + std::max(2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW);
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
         }

@@ -5,9 +5,10 @@
 #include <stdint.h>
 
 // k_step_fast keeps a cell's y this many floats after its x in LDS (x rows of the two environments first), a
-// compile-time distance so that one address serves both; it must hold two rows of up to 1024 cells.
+// compile-time distance (a multiple of 64) so that one address serves both; it must hold two rows of up to 1024 cells
+// and the 64 own-position entries that follow them.
 #ifndef ASM_GY_OFF
-#define ASM_GY_OFF 2048
+#define ASM_GY_OFF 2112
 #endif
 
 namespace asmenv {

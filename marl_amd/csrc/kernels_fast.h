@@ -29,7 +29,9 @@ __device__ __forceinline__ float wrapped_s32(float rx, float ry, float hw, float
 struct FastLds {
     float *px, *py, *vx, *vy;      // [64]   slot = (env half << 5) | agent
     float *g;                      // x rows of the two environments at [0, 2 NGP), their y rows ASM_GY_OFF floats further on
-                                   // (a compile-time distance: one address serves both coordinates of a cell); cells >= n_g hold 1e30
+                                   // (a compile-time distance: one address serves both coordinates of a cell); cells >= n_g hold 1e30.
+                                   // Entry 2 NGP + l is lane l's own position: the "cell" an empty observation slot reads, so that
+                                   // its relative position comes out as +0 without a select
     unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
     unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
     uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
@@ -44,7 +46,7 @@ __device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevPara
     float *f = reinterpret_cast<float *>(smem);
     L.px = f; L.py = f + 64; L.vx = f + 128; L.vy = f + 192;
     L.g = f + 256;
-    L.mask = reinterpret_cast<unsigned *>(L.g + ASM_GY_OFF + 2 * P.NGP);
+    L.mask = reinterpret_cast<unsigned *>(L.g + ASM_GY_OFF + 2 * P.NGP + 64);   // 64: the y halves of the lanes' own-position entries
     L.occ = L.mask + 64 * P.MW;
     L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
     L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // ---- P3: agent x cell pass on the NEW state, words split over the waves ------------
     const float pxf = L.px[l], pyf = L.py[l];
     const double px = pxf, py = pyf;
+    if (sub == T - 1) { L.g[2 * NGP + l] = pxf; L.g[ASM_GY_OFF + 2 * NGP + l] = pyf; }   // read in P6, several barriers on
     // obs[row * n_a + agent] of this lane's environment, written with buffer stores: resource = the block of the
     // workgroup's two environments, vector offset = the lane's column, scalar offset = the row; a row store then
     // needs no vector address arithmetic
@@ -659,33 +662,38 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const bool rew_on = active && in_flag && n_after > 0;
     float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
     {
+        f32x2 fn2 = {0.f, 0.f};
         const int gb = P.obs_dim - cap * 2;
         constexpr int RB = 10;                                      // slots per round: indices, coordinates, then math + stores
         if (active) {
+            const int own = (2 - es) * NGP + l;                     // an empty slot reads the lane's own position: x - x = +0 (CPP:329-333 zeros)
+            const f32x2 p2 = {pxf, pyf};
             for (int kb = k0; kb < k1; kb += RB) {
-                int cell[RB]; float cx[RB], cy[RB]; bool have[RB];
+                int cell[RB]; f32x2 c2[RB]; bool have[RB];
 #pragma unroll
                 for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q];   // one batch of LDS reads; entries past k1 (the list is padded by RB) are masked below
 #pragma unroll
-                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? cell[q] : 0; }
+                for (int q = 0; q < RB; ++q) { have[q] = kb + q < n_out && kb + q < k1; cell[q] = have[q] ? cell[q] : own; }
 #pragma unroll
-                for (int q = 0; q < RB; ++q) { cx[q] = gxe[cell[q]]; cy[q] = gye[cell[q]]; }
+                for (int q = 0; q < RB; ++q) { c2[q].x = gxe[cell[q]]; c2[q].y = gye[cell[q]]; }
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     const int k = kb + q;
                     if (k < k1) {
-                        const float gx = have[q] ? cx[q] - pxf : 0.f, gy = have[q] ? cy[q] - pyf : 0.f;   // CPP:285-286
+                        const f32x2 g2 = c2[q] - p2;                // CPP:285-286
 #ifndef ASM_EXP_NOSTORE
-                        ostore(gb + 2 * k, gx); ostore(gb + 2 * k + 1, gy);
+                        ostore(gb + 2 * k, g2.x); ostore(gb + 2 * k + 1, g2.y);
 #endif
                         // psi = (1 + cos(pi z / d_sen)) / 2 (CPP:1017-1025); v_cos_f32 takes revolutions
-                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(g2.y, g2.y, g2.x * g2.x));
                         const float psi = have[q] ? __builtin_fmaf(0.5f, __builtin_amdgcn_cosf(z * P.inv2dsen_f), 0.5f) : 0.f;
-                        fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
+                        const f32x2 psi2 = {psi, psi};
+                        fn2 = __builtin_elementwise_fma(psi2, g2, fn2); fden += psi;
                     }
                 }
             }
         }
+        fn0 = fn2.x; fn1 = fn2.y;
         if (IDX >= 1 && sensed_g) {
             // sensed_index rows (CPP:341-345), copied from the LDS lists agent by agent so that the 64 lanes write
             // 64 consecutive entries; the agents are dealt out to the waves
