@@ -52,7 +52,7 @@ def measured_traffic(E: int, n_a: int, S: int):
     return None
 
 
-def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 12.0):
+def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 20.0):
     """The CPU path on a bounded sample of the same workload, all host threads we may use."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import numpy as np
