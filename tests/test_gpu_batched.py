@@ -624,3 +624,38 @@ def test_periodic_arena_kernels_agree(torch_cuda, monkeypatch):
     assert torch.allclose(outs["4"][1], outs["0"][1], rtol=1e-5, atol=1e-9)
     assert crossed
     assert (outs["4"][0][-1][3].abs() <= 2.4).all()
+
+
+@pytest.mark.parametrize("boundary", [True, False])
+def test_index_list_levels_agree(torch_cuda, boundary):
+    """The step kernel is compiled once per index-list level (none / sensed_index / both).  The oracle comparisons
+    above run with both lists; here the three builds step the same episode, half of the environments packed into
+    their shapes (occupancy filter, sub-sampling), and every other output must be bit-equal, so that parity carries
+    over to the build without lists that the throughput path uses."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    E, n_a, steps = 48, 30, 25
+    runs = {}
+    for level in (True, "sensed", False):
+        env = BatchedAssemblyEnv(E, n_a, seed=61, is_boundary=boundary, keep_indices=level)
+        env.reset()
+        g = torch.Generator(device="cuda").manual_seed(9)
+        cell = (torch.rand(E, n_a, device="cuda", generator=g) * env.n_g[:, None]).long()
+        pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a)) + 0.03 * torch.randn(E, 2, n_a, device="cuda", generator=g)
+        p = env.p.clone(); p[::2] = pos[::2]
+        env.p.copy_(p); env.observe()
+        rec = [[x.clone() for x in (env.obs, env.neighbor_index, env.in_flags)]]
+        for t in range(steps):
+            obs, rew, _, _, prior = env.step(env.random_actions())
+            rec.append([x.clone() for x in (obs, rew, prior, env.p, env.dp, env.neighbor_index, env.in_flags, env.stats)])
+            if level:
+                rec[-1].append(env.sensed_index.clone())
+        runs[level] = rec
+        if level is True:
+            assert (env.in_flags[::2].sum() > 0) and (env.occupied_index >= 0).any() and (env.sensed_index[..., -1] >= 0).any()
+    for t in range(steps + 1):
+        for k in range(len(runs[False][t])):
+            assert torch.equal(runs[True][t][k], runs[False][t][k]), f"none vs both: step {t} output {k}"
+            assert torch.equal(runs[True][t][k], runs["sensed"][t][k]), f"sensed vs both: step {t} output {k}"
+        if t:
+            assert torch.equal(runs[True][t][-1], runs["sensed"][t][-1]), f"sensed_index: step {t}"
