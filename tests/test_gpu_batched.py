@@ -659,3 +659,33 @@ def test_index_list_levels_agree(torch_cuda, boundary):
             assert torch.equal(runs[True][t][k], runs["sensed"][t][k]), f"sensed vs both: step {t} output {k}"
         if t:
             assert torch.equal(runs[True][t][-1], runs["sensed"][t][-1]), f"sensed_index: step {t}"
+
+
+def test_index_list_levels_agree_full_size(torch_cuda):
+    """The same at the benchmark's size (4096 environments x 30 agents, two shards of 2048 on two streams as the
+    bench steps them): the build without lists against the build with both, every step's observation, reward and
+    prior bit-equal, and the final state and statistics."""
+    torch = torch_cuda
+    from marl_amd.sharding import StreamShards
+    E, n_a, steps = 4096, 30, 30
+    runs = {}
+    for level in (True, False):
+        shards = StreamShards(E, n_a, parts=2, seed=226, keep_indices=level)
+        shards.reset(0)
+        acts = shards.on_each(lambda k, env: [env.random_actions(step=t).clone() for t in range(steps)])
+        rec = []
+        for t in range(steps):
+            shards.step([a[t] for a in acts])
+            shards.synchronize()
+            rec.append([torch.cat([getattr(env, name) for env in shards.envs]) for name in ("obs", "reward", "a_prior")])
+            torch.cuda.synchronize()                              # the copies ran on the default stream
+        final = [torch.cat([getattr(env, name) for env in shards.envs])
+                 for name in ("p", "dp", "neighbor_index", "in_flags", "nearest_cell", "stats")]
+        torch.cuda.synchronize()
+        runs[level] = (rec, final)
+    for t in range(steps):
+        for k in range(3):
+            assert torch.equal(runs[True][0][t][k], runs[False][0][t][k]), f"step {t} output {k}"
+    for k in range(6):
+        assert torch.equal(runs[True][1][k], runs[False][1][k]), f"final {k}"
+    assert runs[False][1][3].sum() > 0                             # some agents did get inside their shapes
