@@ -2,7 +2,7 @@
 float32 state, as in tests/gpu_util.py), in the reference's reset regime and with the agents packed inside their
 shapes.  Indices bit-exact, values to one float32 rounding, like the GPU tests, but over many more agent-steps.
 
-    python tools/soak_oracle.py [E] [steps]
+    python tests/soak_oracle.py [E] [steps]      (not collected by pytest; part of the checker side, like the tests)
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")]
+sys.path[:0] = [REPO, os.path.join(REPO, "oracle"), os.path.dirname(os.path.abspath(__file__))]
 import torch  # noqa: E402
 from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
 from gpu_util import cfg_from_env, teacher_forced_step  # noqa: E402
