@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             // whose first rank lies in [k0, k1) (found above, so it starts without skipping anything).  The
             // lane's next QN non-empty words are fetched into registers in one batch, so the loop below runs
             // without waiting on LDS; a lane that needs more words finishes in the second loop.
-            constexpr int QN = 6;
+            constexpr int QN = 5;
             bool busy = found && bst < k1;
             int rank = bst;
             nz &= 0xFFFFFFFFu << wst;
