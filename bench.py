@@ -28,7 +28,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 EPISODE_LENGTH = 200           # marl_llm/cfg/assembly_cfg.py:192
-SETTLE_STEPS = 400             # untimed steps of continuous load before the step time is steady
+SETTLE_STEPS = int(os.environ.get("MARL_AMD_BENCH_SETTLE", "1200"))   # untimed steps of continuous load before the step time is steady
 
 
 def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
@@ -226,7 +226,7 @@ def main():
     # one-time costs (lazy kernel loading, RCCL communicator set-up) stay out of the timing
     barrier()
     mark("environment reset, actions drawn")
-    # The step time settles only after about 400 steps (25 ms) of continuous load (clock ramp): when fewer warm-up
+    # The step time settles only after about 40 ms (1000 steps) of continuous load (clock ramp): when fewer warm-up
     # steps are asked for, the difference is stepped first and the environments are put back to their episode-0 state.
     if W < SETTLE_STEPS:
         for t in range(SETTLE_STEPS - W):
