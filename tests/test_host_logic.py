@@ -112,3 +112,22 @@ def test_wrapper_metrics_match_reference_values():
         assert m["num_collisions"] == int(z[f"num_collisions_{k}"])
         for key, zk in (("distribution_uniformity",) * 2, ("voronoi_uniformity",) * 2, ("avg_distance_to_target",) * 2):
             assert m[key] == pytest.approx(float(z[f"{zk}_{k}"]), rel=1e-12, abs=1e-14)
+
+
+def test_bench_roofline_inputs():
+    """The bench's roofline figures: algorithmic bytes per agent-step (872 + 8 n_g / n_a), the committed counter
+    summary it quotes the measured traffic from (only for the workload the counters were taken on), and the
+    committed bench line's internal consistency (achieved = launches in flight x bytes per launch / launch time)."""
+    import json
+    import bench
+    assert bench.b_alg_per_agent_step(30, 500.0) == pytest.approx(872 + 8 * 500 / 30)
+    t = bench.measured_traffic(4096, 30, 2)
+    assert t is not None and t["hbm_bytes_per_launch"] > 0.9 * 2048 * 30 * bench.b_alg_per_agent_step(30, 511.8)
+    assert bench.measured_traffic(4096, 31, 2) is None
+    with open(os.path.join(REPO, "profiles", "r01_bench_default.json")) as f:
+        line = json.load(f)
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    assert r["achieved"] == pytest.approx(r["launches_in_flight"] * r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9)
+    assert line["value"] == pytest.approx(line["config"]["global_envs"] * line["config"]["agents"] / (line["ms_per_step"] * 1e-3))
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] >= 1
