@@ -10,8 +10,12 @@ N > 1: launched by torch.distributed.run, one rank per GPU; environments are sha
 by global id, no data-path collective; one RCCL all-reduce of the 8-value
 episode-statistics vector per 200-step episode.
 
+Timing: R windows of exactly --steps steps each, back to back, bracketed by barrier +
+synchronize; window boundaries are HIP events on the shard streams and the step time
+is the median window / --steps (max over ranks).
+
 Rank 0 prints ONE JSON line: whole-job agent-steps/s, the roofline of the dominant
-kernel (k_step) from HIP-event timing, and at N = 1 the CPU baseline (the compiled
+kernel (k_step) derived from that value, and at N = 1 the CPU baseline (the compiled
 reference AssemblyEnv.cpp if oracle/_ref travels with the tree, else our C port)
 timed on the host cores in the same run.
 """
@@ -27,6 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VALU_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x 2.4 GHz)
 EPISODE_LENGTH = 200           # marl_llm/cfg/assembly_cfg.py:192
 SETTLE_STEPS = int(os.environ.get("MARL_AMD_BENCH_SETTLE", "1200"))   # untimed steps of continuous load before the step time is steady
 
@@ -38,17 +43,27 @@ def b_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
     return 872.0 + 8.0 * n_g_mean / n_a
 
 
+def f_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
+    """Algorithmic FLOPs per agent-step (fma = 2, sqrt = 1, cos ~ 20): two nearest-cell passes 2*5*n_g, the
+    environment's cell-occupancy share 5*n_g, contacts 15*(n_a-1), k-NN distances 5*(n_a-1), reward 30*80."""
+    return 15.0 * n_g_mean + 20.0 * (n_a - 1) + 2400.0
+
+
+PMC_FILES = ("r02_pmc.json", "r02_c4_pmc.json", "r01_pmc.json")
+
+
 def measured_traffic(E: int, n_a: int, S: int):
-    """HBM bytes per k_step launch and VALU busy from the committed rocprofv3 PMC passes (profiles/r01_pmc.json),
-    if they were taken on this workload; None otherwise (counters cannot be read from inside this process)."""
-    path = os.path.join(REPO, "profiles", "r01_pmc.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t["workload"] == {"envs_per_gpu": E, "agents": n_a, "streams": S}:
-            return t
-    except (OSError, ValueError, KeyError):
-        pass
+    """HBM bytes per step-kernel launch and VALU busy from the committed rocprofv3 PMC passes (profiles/*_pmc.json),
+    if one was taken on this workload; None otherwise (counters cannot be read from inside this process)."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                t = json.load(f)
+            if t["workload"] == {"envs_per_gpu": E, "agents": n_a, "streams": S}:
+                t["source"] = "profiles/" + name
+                return t
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
@@ -103,6 +118,9 @@ def main():
     ap.add_argument("--agents", type=int, default=30)
     ap.add_argument("--graph-steps", type=int, default=0,
                     help="steps per captured HIP graph (must divide the episode length of 200; 0 = launch every step from the host)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed windows of --steps steps each, run back to back; the reported step time is the median "
+                         "window (default: at least 5, and enough for 400 timed steps in total)")
     ap.add_argument("--streams", type=int, default=2,
                     help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -240,61 +258,94 @@ def main():
     mark("warm-up all-reduce done")
     barrier()
     mark("barrier passed, timing")
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
+    # R windows of exactly K steps each, back to back (nothing synchronises between them), bracketed as a whole by
+    # barrier + synchronize.  Window boundaries are HIP events on every shard stream; a window's duration is the
+    # longest of its per-stream intervals, and the reported step time is the MEDIAN window / K: the first window
+    # absorbs the pipeline fill after the barrier and the last one the drain, whatever K is.
+    R = args.repeats if args.repeats > 0 else max(5, -(-400 // max(K, 1)))
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(R + 1)] for _ in range(S)]
     t0 = time.perf_counter()
     for k in range(S):
         evs[k][0].record(shards.streams[k])
-    run_steps(K, W)
-    for k in range(S):
-        evs[k][1].record(shards.streams[k])
+    for r in range(R):
+        run_steps(K, W + r * K)
+        for k in range(S):
+            evs[k][r + 1].record(shards.streams[k])
     barrier()
     mark("timed region done")
-    wall = time.perf_counter() - t0
-    # per stream: K launches back to back -> the average launch duration of the step kernel on that stream
-    ev_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S
-    tmax = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    wall_all = time.perf_counter() - t0
+    win_ms = sorted(max(evs[k][r].elapsed_time(evs[k][r + 1]) for k in range(S)) for r in range(R))
+    med_ms = win_ms[R // 2] if R % 2 else 0.5 * (win_ms[R // 2 - 1] + win_ms[R // 2])
+    # per stream: launches back to back -> the launch period of the step kernel on that stream, over all windows
+    ev_ms = sum(evs[k][0].elapsed_time(evs[k][R]) for k in range(S)) / S / R
+    tmax = torch.tensor([med_ms * 1e-3, wall_all], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax)
+    wall, wall_all = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
         agent_steps = world * E * n_a * K
         value = agent_steps / wall
         b_alg = b_alg_per_agent_step(n_a, n_g_mean)
-        resets = sum(1 for t in range(W, W + K) if (t + 1) % EPISODE_LENGTH == 0)
-        kern_ms = ev_ms / K                                   # step launches run back to back on each stream
+        f_alg = f_alg_per_agent_step(n_a, n_g_mean)
+        resets = sum(1 for t in range(W, W + R * K) if (t + 1) % EPISODE_LENGTH == 0)
+        kern_ms = ev_ms / K                                   # launch period of one stream
         per_launch = E / S * n_a                              # agent-steps of one launch (one shard)
-        # S launches are in flight at any time, so the device moves S launches' bytes per launch duration
-        achieved = S * per_launch * b_alg / (kern_ms * 1e-3) / 1e9
+        per_gpu = value / world                               # agent-steps/s of one GPU
+        # The roofline that bounds the step: arithmetic intensity F_alg / B_alg against the machine balance
+        # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B).  30 agents: 10.4 FLOP/B -> HBM; 1024 agents: 34.7 -> fp32 VALU.
+        valu_bound = f_alg / b_alg > VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         tr = measured_traffic(E, n_a, S)
+        if valu_bound:
+            achieved, peak, unit = per_gpu * f_alg / 1e12, VALU_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = per_gpu * b_alg / 1e9, HBM_PEAK_GBS, "GB/s"
+        if n_a == 30 and E == 4096:
+            which = "configs[1] of BASELINE.json"
+        elif n_a == 30 and E == 8192:
+            which = "one rank's shard of configs[2] of BASELINE.json (65536 envs over 8 GPUs)"
+        elif n_a == 1024 and E == 256:
+            which = "configs[3] of BASELINE.json (large swarm)"
+        else:
+            which = "not a BASELINE.json configuration"
         out = {
-            "metric": "agent-steps/sec (whole node) for batched 30-agent assembly envs at 1/2/4/8 GPUs",
+            "metric": f"agent-steps/sec (whole node) for batched {n_a}-agent assembly envs at 1/2/4/8 GPUs",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "timing": {"clock": "HIP events on the shard streams at the window boundaries; value = agent-steps of one "
+                                "window / median window duration, max over ranks",
+                       "windows": R, "steps_per_window": K, "window_ms_min_median_max": [win_ms[0], med_ms, win_ms[-1]],
+                       "host_wall_ms_per_step_all_windows": wall_all / (R * K) * 1e3,
+                       "untimed_settle_steps": max(SETTLE_STEPS, W)},
             "config": {"workload": f"{E} parallel assembly envs x {n_a} agents per GPU, random U(-1,1) actions "
-                                   f"(configs[1] of BASELINE.json), 7 reference shapes, {'periodic arena' if args.periodic else 'walls on'}, llm_rl prior on"
+                                   f"({which}), 7 reference shapes, {'periodic arena' if args.periodic else 'walls on'}, llm_rl prior on"
                                    + (", agents started inside their shapes" if args.regime == "packed" else ""),
                        "envs_per_gpu": E, "agents": n_a, "global_envs": world * E, "mean_n_g": n_g_mean,
                        "episode_length": EPISODE_LENGTH, "episode_resets_in_timed_region": resets,
                        "state": "float32 in HBM; decisions evaluated in float64",
                        "streams_per_gpu": S, "steps_per_hip_graph": C,
                        "parallelism": f"env-sharded x{world} GPUs x{S} HIP streams, RCCL all-reduce of 8 doubles per episode"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         # PMC bytes per launch x launches in flight / this run's launch time, same unit as `achieved`
+            # achieved = (agent-steps/s of one GPU) x algorithmic bytes (or FLOPs) per agent-step; frac = achieved / peak
+            "roofline": {"bound": "valu" if valu_bound else "hbm", "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak,
+                         # PMC bytes per launch x launches in flight / this run's launch period, in GB/s
                          "traffic": (S * tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
                          "traffic_bytes_per_launch": tr["hbm_bytes_per_launch"] if tr else None,
-                         "traffic_source": "profiles/r01_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)" if tr else None,
+                         "traffic_source": (tr["source"] + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)") if tr else None,
                          # rocprof's VALUBusy formula on the same PMC passes (counters serialise the launches, so
-                         # this is one launch alone on the chip): the kernel is bound by instruction issue
+                         # this is one launch alone on the chip)
                          "valu_busy_one_launch": tr.get("valu_busy") if tr else None,
-                         "launches_in_flight": S, "achieved_per_launch": achieved / S,
-                         "alg_bytes_per_launch": per_launch * b_alg,
-                         "kernel": "k_step_fast / k_step (asm_batch_step_f32)", "avg_launch_ms": kern_ms,
-                         # avg_launch_ms: HIP events on each shard's stream around its K back-to-back launches, / K, i.e. the
-                         # launch period of a stream = kernel duration (rocprofv3 --kernel-trace: profiles/) + dispatch gap
-                         "alg_bytes_per_agent_step": b_alg, "agent_steps_per_launch": per_launch},
+                         "issue_bound_note": "the 30-agent step is limited by vector-instruction issue, not by bandwidth "
+                                             "(see valu_busy_one_launch); its roofline by bytes is HBM",
+                         "launches_in_flight": S, "alg_bytes_per_launch": per_launch * b_alg,
+                         "alg_flops_per_launch": per_launch * f_alg,
+                         "kernel": "k_step_fast / k_step (asm_batch_step_f32)",
+                         # HIP events on each shard's stream around all its timed launches, / launches: the launch period
+                         # of a stream = kernel duration (rocprofv3 --kernel-trace: profiles/) + dispatch gap
+                         "avg_launch_ms": kern_ms,
+                         "alg_bytes_per_agent_step": b_alg, "alg_flops_per_agent_step": f_alg,
+                         "agent_steps_per_launch": per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n_a, shards.envs[0].r_avoid)

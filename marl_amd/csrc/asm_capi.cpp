@@ -14,7 +14,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <string>
 
 #include "asm_kernels.h"
 
@@ -22,13 +21,11 @@ using asmenv::DevParams;
 
 namespace {
 
-thread_local std::string g_err;
+thread_local char g_err[512];                                // fixed storage: reporting an error allocates nothing
 
 int fail(int code, const char *fmt, ...)
 {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g_err = buf;
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
     return code;
 }
 
@@ -59,8 +56,37 @@ double thr_le(double t)
 
 int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// MARL_AMD_FAST_T (tuning / test knob: waves per workgroup of k_step_fast, 0 = generic kernel), read once per process
+int fast_t_setting()
+{
+    static const int v = [] { const char *ov = std::getenv("MARL_AMD_FAST_T"); return ov ? std::atoi(ov) : 4; }();
+    return v;
+}
+
 // Launch geometry + thresholds.  state_bytes = sizeof(S).
+int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out);
+
+// The derivation walks double-precision neighbours for the exact thresholds; a run steps with the same few
+// (parameters, E) combinations over and over, so the last results are kept per thread.
 int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out)
+{
+    struct Slot { asm_params prm; int E; size_t sb; DevParams P; bool used; };
+    constexpr int N = 8;
+    thread_local Slot cache[N];
+    thread_local int next = 0;
+    if (prm)
+        for (int k = 0; k < N; ++k)
+            if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && !std::memcmp(&cache[k].prm, prm, sizeof *prm)) {
+                *out = cache[k].P;
+                return 0;
+            }
+    if (int rc = derive_dev_params(prm, E, state_bytes, out)) return rc;
+    Slot &s = cache[next]; next = (next + 1) % N;
+    std::memcpy(&s.prm, prm, sizeof *prm); s.E = E; s.sb = state_bytes; s.P = *out; s.used = true;
+    return 0;
+}
+
+int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out)
 {
     if (!prm) return fail(1, "asm_params is NULL");
     if (E < 1) return fail(1, "E = %d: need at least one environment", E);
@@ -119,8 +145,7 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     if (state_bytes == 4 && prm->n_a <= 32 && P.W <= 32 && prm->n_g_max % 32 == 0 && P.n_obs <= 4096 && ((P.n_obs - 1) & 1)) {
         const int blocks = (E + 1) / 2;
         (void)blocks;
-        int T = 4;                                                   // fastest measured schedule at every batch size from 2048 to 32768 environments
-        if (const char *ov = std::getenv("MARL_AMD_FAST_T")) T = std::atoi(ov);   // tuning / test knob: 0 = generic kernel
+        int T = fast_t_setting();                                    // 4: fastest measured schedule at every batch size from 2048 to 32768 environments
         if (P.periodic && T != 4) T = 0;                            // the periodic arena is built for 4 waves only
         if (T == 1 || T == 2 || T == 4) {
             // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on, 64 own-position entries; masks; occupancy;
@@ -192,7 +217,7 @@ void compat_params(asm_params *a, int n_a, int n_g, int topo, int n_obs, int n_o
 
 [[noreturn]] void die_msg(const char *fn)
 {
-    std::fprintf(stderr, "libAssemblyEnv (HIP): %s: %s\n", fn, g_err.c_str());
+    std::fprintf(stderr, "libAssemblyEnv (HIP): %s: %s\n", fn, g_err);
     std::abort();
 }
 
@@ -215,7 +240,7 @@ int asm_obs_dim(const asm_params *p)
 }
 
 int asm_abi_version(void) { return ASM_ABI_VERSION; }
-const char *asm_last_error(void) { return g_err.c_str(); }
+const char *asm_last_error(void) { return g_err; }
 
 int asm_device_count(void)
 {
