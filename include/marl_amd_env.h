@@ -74,6 +74,25 @@ void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_inp
                           double *grid_center_input, int *neighbor_index_input, double d_sen,
                           double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim);
 
+/*
+ * _get_observation for callers that cannot allocate device memory: code running under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, layouts and
+ * results as _get_observation above (bit for bit); returns 0, or an error code with the text in asm_last_error().
+ * The device staging area is a fixed 4 MiB array inside the library (one copy per GPU, held until the process
+ * ends) instead of a workspace that grows on demand; a call whose arrays need more (about n_a = 1024 with the
+ * default list capacities) is rejected.  The call makes no hipMalloc / hipFree / stream creation; it runs on the
+ * legacy default stream of the current device and returns when the outputs are in the caller's arrays.  Every call
+ * on one GPU uses that GPU's array: calls on the same GPU must not overlap (calls through this entry point are
+ * serialised by the library; other work that touches the array does not exist).
+ */
+int asm_get_observation_noalloc(double *p_input, double *dp_input, double *heading_input, double *obs_input,
+                                double *boundary_pos_input, double *grid_center_input,
+                                int *neighbor_index_input, int *in_flags_input, int *sensed_index_input,
+                                int *occupied_index_input, double d_sen, double r_avoid, double l_cell,
+                                double Vel_max, int topo_nei_max, int num_obs_grid_max,
+                                int num_occupied_grid_max, int n_a, int n_g, int obs_dim_agent, int dim,
+                                bool *condition);
+
 /* ------------------------------------------------------------------ (B) -- */
 
 /* Environment constants: the attributes ENV:17-89, 91-149, 194 that the step reads. */

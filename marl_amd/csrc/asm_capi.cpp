@@ -521,4 +521,90 @@ void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, doubl
     get(a_prior_io, o_a, 2 * na);
 }
 
+// ------------------------------------------------------------------------------
+// _get_observation for callers that cannot allocate (HIP graph capture around them, serving loops, harnesses that
+// forbid hipMalloc): the device staging area of the call is a file-scope device array instead of the growing
+// hipMalloc'ed workspace above, the copies go straight between the caller's arrays and that array, and the work
+// runs on the legacy default stream.  Nothing here allocates, frees or creates a stream.
+//
+// In host code the array's name is only a handle for hipGetSymbolAddress; the address kernels and copies use is
+// looked up once per device (each GPU has its own copy at its own address) and kept in g_scratch_ptr.
+#define ASM_NOALLOC_SCRATCH_BYTES (4u << 20)
+static __device__ __align__(256) unsigned char scratch[ASM_NOALLOC_SCRATCH_BYTES];
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES];           // device address of `scratch`, per device
+std::mutex g_noalloc_mutex;
+}
+
+int asm_get_observation_noalloc(double *p_in, double *dp_in, double *heading_in, double *obs_io, double *bpos,
+                                double *grid_in, int *nbr_io, int *inflags_io, int *sensed_io, int *occupied_io,
+                                double d_sen, double r_avoid, double l_cell, double Vel_max, int topo_nei_max,
+                                int num_obs_grid_max, int num_occupied_grid_max, int n_a, int n_g, int obs_dim_agent,
+                                int dim, bool *condition)
+{
+    (void)Vel_max;
+    std::lock_guard<std::mutex> lk(g_noalloc_mutex);
+    if (!p_in || !dp_in || !heading_in || !obs_io || !bpos || !grid_in || !nbr_io || !inflags_io || !sensed_io ||
+        !occupied_io || !condition)
+        return fail(1, "asm_get_observation_noalloc: NULL pointer");
+    if (dim != 2) return fail(1, "dim = %d: only 2 is supported", dim);
+    if (n_g < 1) return fail(1, "n_g = %d", n_g);
+    int dev = -1;
+    hipError_t he = hipGetDevice(&dev);
+    if (he != hipSuccess) return hip_fail((int)he, "hipGetDevice");
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(1, "device %d: at most %d devices are supported", dev, NOALLOC_MAX_DEVICES);
+    if (!g_scratch_ptr[dev]) {                                // first call on this device, which is the current one
+        void *ptr = nullptr;
+        he = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (he != hipSuccess || !ptr) return hip_fail((int)he, "hipGetSymbolAddress(scratch)");
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(ptr);
+    }
+    unsigned char *const ws = g_scratch_ptr[dev];
+
+    asm_params a; compat_params(&a, n_a, n_g, topo_nei_max, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
+    a.is_boundary = condition[0] ? 0 : 1; a.is_con_self_state = condition[2] ? 1 : 0;
+    DevParams P;
+    if (int rc = make_dev_params(&a, 1, sizeof(double), &P)) return rc;
+    P.cartesian = condition[1] ? 1 : 0;
+    P.obs_dim = obs_dim_agent;
+    const int min_rows = (P.con_self ? 4 : 0) + 24 + (P.cartesian ? 4 + 2 * P.n_obs : 6);
+    if (obs_dim_agent < min_rows) return fail(1, "obs_dim_agent = %d < %d", obs_dim_agent, min_rows);
+    const size_t na = (size_t)n_a, ng = (size_t)n_g;
+    Arena A;
+    const size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_h = A.take<double>(2 * na);
+    const size_t o_g = A.take<double>(2 * ng), o_ng = A.take<int>(1), o_lc = A.take<double>(1);
+    const size_t o_obs = A.take<double>((size_t)obs_dim_agent * na), o_nbr = A.take<int>(na * 6), o_in = A.take<int>(na);
+    const size_t o_near = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_occ = A.take<int>(na * P.n_occ);
+    if (A.off > ASM_NOALLOC_SCRATCH_BYTES)
+        return fail(1, "asm_get_observation_noalloc: n_a = %d, n_g = %d, obs_dim = %d, list capacities %d / %d need %zu bytes of "
+                       "staging; the fixed device array holds %u", n_a, n_g, obs_dim_agent, P.n_obs, P.n_occ, A.off,
+                    (unsigned)ASM_NOALLOC_SCRATCH_BYTES);
+#define NOALLOC_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail((int)_e, #call); } while (0)
+    // blocking copies on the legacy default stream: each is ordered against the kernel below without further calls
+    NOALLOC_HIP(hipMemcpy(ws + o_p, p_in, 2 * na * sizeof(double), hipMemcpyHostToDevice));
+    NOALLOC_HIP(hipMemcpy(ws + o_dp, dp_in, 2 * na * sizeof(double), hipMemcpyHostToDevice));
+    NOALLOC_HIP(hipMemcpy(ws + o_h, heading_in, 2 * na * sizeof(double), hipMemcpyHostToDevice));
+    NOALLOC_HIP(hipMemcpy(ws + o_g, grid_in, 2 * ng * sizeof(double), hipMemcpyHostToDevice));
+    NOALLOC_HIP(hipMemcpy(ws + o_ng, &n_g, sizeof(int), hipMemcpyHostToDevice));
+    NOALLOC_HIP(hipMemcpy(ws + o_lc, &l_cell, sizeof(double), hipMemcpyHostToDevice));
+    // the array keeps the previous call's contents: the observation must start at zero (CPP:49)
+    NOALLOC_HIP(hipMemsetAsync(ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double), nullptr));
+    auto at_ws = [ws](size_t off) { return ws + off; };
+    int rc = asmenv::launch_observe<double>(
+        P, reinterpret_cast<double *>(at_ws(o_p)), reinterpret_cast<double *>(at_ws(o_dp)),
+        reinterpret_cast<double *>(at_ws(o_h)), reinterpret_cast<double *>(at_ws(o_g)), reinterpret_cast<int *>(at_ws(o_ng)),
+        reinterpret_cast<double *>(at_ws(o_lc)), reinterpret_cast<int *>(at_ws(o_nbr)), reinterpret_cast<int *>(at_ws(o_in)),
+        reinterpret_cast<int *>(at_ws(o_near)), reinterpret_cast<double *>(at_ws(o_obs)), nullptr,
+        reinterpret_cast<int *>(at_ws(o_sen)), reinterpret_cast<int *>(at_ws(o_occ)), nullptr);
+    if (rc) return hip_fail(rc, "asm_get_observation_noalloc kernel launch");
+    NOALLOC_HIP(hipMemcpy(obs_io, ws + o_obs, (size_t)obs_dim_agent * na * sizeof(double), hipMemcpyDeviceToHost));
+    NOALLOC_HIP(hipMemcpy(nbr_io, ws + o_nbr, na * 6 * sizeof(int), hipMemcpyDeviceToHost));
+    NOALLOC_HIP(hipMemcpy(inflags_io, ws + o_in, na * sizeof(int), hipMemcpyDeviceToHost));
+    NOALLOC_HIP(hipMemcpy(sensed_io, ws + o_sen, na * P.n_obs * sizeof(int), hipMemcpyDeviceToHost));
+    NOALLOC_HIP(hipMemcpy(occupied_io, ws + o_occ, na * P.n_occ * sizeof(int), hipMemcpyDeviceToHost));
+#undef NOALLOC_HIP
+    return 0;
+}
+
 }  // extern "C"
