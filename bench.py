@@ -171,12 +171,7 @@ def main():
                           keep_indices={None: False, "both": True, "sensed": "sensed"}[args.keep_indices], is_boundary=not args.periodic)
 
     def all_reduce_stats(v):
-        # gloo rehearsal only: the sum goes through the host (gloo's device-tensor path stalls when two ranks share a
-        # GPU that is busy on another stream); with RCCL the device vector is reduced in place, asynchronously
-        if world > 1 and backend != "nccl":
-            h = v.cpu()
-            dist.all_reduce(h)
-            return v.copy_(h)
+        # with RCCL the device vector is reduced in place, asynchronously (a gloo rehearsal goes through the host)
         return reduce_episode_stats(v)
 
     def reset_one(k, env, episode=None):

@@ -149,10 +149,13 @@ class BatchedAssemblyEnv:
                 tuple(a.shape) != (self.E, 2, self.n_a):
             raise ValueError(f"actions must be a contiguous float32 tensor of shape {(self.E, 2, self.n_a)} on {self.device}")
         prior = self.a_prior if self.training_method == "llm_rl" else None
-        # the argument list only changes when an output tensor is re-pointed (DeviceReplay does that); building
-        # 17 ctypes pointers per call would otherwise cost more host time than a short launch takes on the GPU
-        sig = (self.obs.data_ptr(), self.reward.data_ptr(), 0 if prior is None else prior.data_ptr(), self.p.data_ptr(),
-               self.dp.data_ptr())
+        # the argument list only changes when a tensor attribute is re-pointed (DeviceReplay does that with the
+        # outputs); building 17 ctypes pointers per call would otherwise cost more host time than a short launch
+        # takes on the GPU.  Every tensor the kernel touches is part of the signature, so `env.x = other_tensor`
+        # is always honoured.
+        sig = tuple(0 if t is None else t.data_ptr() for t in (
+            self.obs, self.reward, prior, self.p, self.dp, self.grid_center, self.n_g, self.l_cell, self.neighbor_index,
+            self.in_flags, self.nearest_cell, self.sensed_index, self.occupied_index, self.stats))
         if self._step_sig != sig:
             self._step_sig = sig
             self._step_args = [C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), None, _ptr(self.grid_center),

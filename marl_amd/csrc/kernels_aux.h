@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_metrics(int n_a, int NGP, double r_half
     __shared__ double px[ASM_MAX_AGENTS], py[ASM_MAX_AGENTS], md[ASM_MAX_AGENTS], mg[ASM_MAX_AGENTS];
     __shared__ int cnt[ASM_MAX_AGENTS];
     __shared__ int covered, contacts;
-    const int e = blockIdx.x, tid = threadIdx.x, n_g = ng_g[e];
+    const int e = blockIdx.x, tid = threadIdx.x, n_g = clamp_ng(ng_g[e], NGP);
     const float *gx = grid_g + (size_t)e * 2 * NGP, *gy = gx + NGP;
     for (int j = tid; j < n_a; j += 256) {
         px[j] = (double)p_g[(size_t)e * 2 * n_a + j]; py[j] = (double)p_g[(size_t)e * 2 * n_a + n_a + j];
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_metrics(int n_a, int NGP, double r_half
         out[(size_t)e * 5 + (tid == 0 ? 1 : tid == 1 ? 2 : 4)] = r;
     }
     if (tid == 3) {
-        out[(size_t)e * 5 + 0] = (double)covered / n_g;             // WRAP:70
+        out[(size_t)e * 5 + 0] = n_g > 0 ? (double)covered / n_g : 0.0;             // WRAP:70
         out[(size_t)e * 5 + 3] = (double)contacts;
     }
 }

@@ -31,6 +31,9 @@ __device__ __forceinline__ double draw_uniform(uint64_t seed, uint64_t env, uint
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// n_g[e] is caller data in device memory: the kernels read cells [0, min(max(n_g, 0), row length)) whatever it holds
+__device__ __forceinline__ int clamp_ng(int n_g, int n_g_max) { return n_g < 0 ? 0 : (n_g > n_g_max ? n_g_max : n_g); }
+
 // ---- LDS carve ------------------------------------------------------------------
 template <typename S>
 struct EnvLds {

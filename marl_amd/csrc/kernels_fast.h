@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #endif
     // ---- P0: grid and state into LDS (all global loads issued before the first LDS write) ----
     const int e0 = blockIdx.x * 2;
-    const int ng0 = e0 < P.E ? ng_g[e0] : 0, ng1 = e0 + 1 < P.E ? ng_g[e0 + 1] : 0;
+    const int ng0 = e0 < P.E ? clamp_ng(ng_g[e0], P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng_g[e0 + 1], P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     {
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const double var = half_sum(dv * dv) / n_a;
         if (i == 0 && env_ok) {
             double *st = stats_g + (size_t)e * 8;
-            st[2] += covered / n_g;
+            st[2] += n_g > 0 ? covered / n_g : 0.0;                   // WRAP:70; an environment without cells covers nothing
             st[3] += (var - lo) / (hi - lo);                        // WRAP:98-99
             st[4] += cp; st[5] += ds / n_a; st[6] += 1.0;
         }

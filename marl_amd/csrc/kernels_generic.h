@@ -325,7 +325,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 int covered = 0;
                 for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
                 double *st = stats_g + (size_t)e * 8;
-                st[0] += rs; st[1] += rs; st[2] += (double)covered / P.n_g_e;   // rewards are 0 or 1
+                st[0] += rs; st[1] += rs; st[2] += P.n_g_e > 0 ? (double)covered / P.n_g_e : 0.0;   // rewards are 0 or 1
                 st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
                 st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
             }
@@ -342,7 +342,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             int covered = 0;
             for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
             double *st = stats_g + (size_t)e * 8;
-            st[0] += rs; st[1] += rq; st[2] += (double)covered / P.n_g_e;
+            st[0] += rs; st[1] += rq; st[2] += P.n_g_e > 0 ? (double)covered / P.n_g_e : 0.0;
             st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
             st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
         }
@@ -382,7 +382,7 @@ __global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *hea
     const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     EnvLds<S> L = carve<S>(smem, P, es);
-    const int n_g = env_ok ? ng_g[e] : 0;
+    const int n_g = env_ok ? clamp_ng(ng_g[e], P.n_g_max) : 0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     __syncthreads();
@@ -403,7 +403,7 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     const int n_a = P.n_a;
     EnvLds<S> L = carve<S>(smem, P, es);
     STAMP(0);
-    const int n_g = env_ok ? ng_g[e] : 0;
+    const int n_g = env_ok ? clamp_ng(ng_g[e], P.n_g_max) : 0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     __syncthreads();

@@ -119,8 +119,8 @@ class DeviceReplay:
 
     begin_episode() and advance() point the environment's obs / reward / a_prior outputs at the next
     frame of the current slot, so stepping is the push (train_assembly.py:123-125 without the copy).
-    Sample between episodes, as train_assembly.py:141-157 does: while an episode is being written into a
-    reused slot, the transition at the write front pairs a new observation with an old next one.
+    sample() draws from complete slots only: the slot being written (which, when reused, mixes frames of two
+    episodes) is left out until its last step.
     """
 
     def __init__(self, env, episode_length: int, slots: int, seed: int = 0):
@@ -134,14 +134,17 @@ class DeviceReplay:
         self.prior_ring = torch.zeros(self.S, self.T, E, 2, n, **f32) if env.training_method == "llm_rl" else None
         self.rew_ring = torch.zeros(self.S, self.T, E, 1, n, **f32)
         self.slot, self.t = -1, 0
-        self.filled_slots = 0                                       # completed episodes available to sample()
+        self.complete = [False] * self.S                            # per slot: holds one whole episode
         self.seed, self.draws = int(seed), 0
 
     # ---- writing ---------------------------------------------------------------------
     def begin_episode(self) -> None:
-        """Call before env.reset(): the reset's observation becomes frame 0 of the next slot."""
+        """Call before env.reset(): the reset's observation becomes frame 0 of the next slot.  From here until
+        its last step the slot is not sampled (it mixes frames of two episodes); an episode given up early
+        (begin_episode() again before episode_length steps) simply leaves its slot out until it is rewritten."""
         self.slot = (self.slot + 1) % self.S
         self.t = 0
+        self.complete[self.slot] = False
         self.env.obs = self.obs_ring[self.slot, 0]
 
     def action_slot(self) -> torch.Tensor:
@@ -159,8 +162,17 @@ class DeviceReplay:
     def advance(self) -> None:
         """Call after env.step()."""
         self.t += 1
-        if self.t == self.T:                                        # slots fill in order, then are reused in order
-            self.filled_slots = min(self.S, self.filled_slots + 1)
+        if self.t == self.T:
+            self.complete[self.slot] = True
+
+    @property
+    def filled_slots(self) -> int:
+        """Complete episodes available to sample()."""
+        return sum(self.complete)
+
+    @filled_slots.setter
+    def filled_slots(self, n: int) -> None:                         # tests fill the rings by hand
+        self.complete = [k < n for k in range(self.S)]
 
     def __len__(self) -> int:
         """Stored transitions (agent rows), as len(ReplayBufferAgent)."""
@@ -168,6 +180,7 @@ class DeviceReplay:
 
     # ---- sampling --------------------------------------------------------------------
     def draw_indices(self, N: int) -> torch.Tensor:
+        """N transition ids, uniform over the complete slots (with replacement)."""
         if len(self) == 0:
             raise RuntimeError("no completed episode to sample from")
         idx = torch.empty(N, dtype=torch.int64, device=self.env.device)
@@ -175,6 +188,11 @@ class DeviceReplay:
             rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, 0, len(self), N, _ptr(idx), self.env._stream())
         _lib.check(rc, "asm_replay_draw_indices")
         self.draws += 1
+        slots = [k for k in range(self.S) if self.complete[k]]
+        if slots != list(range(len(slots))):                        # a slot in between is being rewritten: renumber
+            per_slot = self.T * self.env.E * self.env.n_a
+            table = torch.tensor(slots, dtype=torch.int64, device=idx.device)
+            idx = table[idx // per_slot] * per_slot + idx % per_slot
         return idx
 
     def gather(self, idx: torch.Tensor, is_prior: bool = True):

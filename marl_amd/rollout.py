@@ -9,12 +9,13 @@ import math
 from typing import Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .batched import BatchedAssemblyEnv
 from .replay import DeviceReplay
-from .sharding import reduce_episode_stats
+from .sharding import all_reduce_sum, reduce_episode_stats
 
 
 class MLPNetwork(nn.Module):
@@ -36,19 +37,62 @@ class MLPNetwork(nn.Module):
         return torch.tanh(out) if self.constrain_out else out
 
 
+class _FlatGrads:
+    """All gradients of a module as views into one contiguous buffer, so that a data-parallel step is ONE
+    all-reduce per optimiser step (the reference's helper, misc.py:33-38, issues one per parameter tensor)."""
+
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self) -> None:
+        self.flat.zero_()                                                  # keeps the views (zero_grad() would drop them)
+
+    def average(self, group=None) -> None:
+        all_reduce_sum(self.flat, group)
+        self.flat.div_(dist.get_world_size(group))
+
+
 class DDPGLearner:
     """One shared DDPG agent (agents.py:9-51; maddpg.py:264-291 builds a single agent type for this
-    environment): policy, critic, their targets, Adam optimisers, Gaussian exploration."""
+    environment): policy, critic, their targets, Adam optimisers, Gaussian exploration.
+
+    data_parallel=True (needs an initialised torch.distributed group; RCCL on GPUs, gloo in CPU tests): every
+    rank updates its own replica on batches from its own environments; rank 0's initial weights are broadcast,
+    and each optimiser step is preceded by one SUM all-reduce of that network's flattened gradient divided by
+    the world size — what maddpg.py:138-139, 179-180 do when update(parallel=True), in two messages of
+    ~0.73 MB per update (hidden 256) instead of sixteen.  Replicas therefore stay bit-identical."""
 
     def __init__(self, obs_dim: int, act_dim: int = 2, hidden_dim: int = 256, lr_actor: float = 1e-4,
-                 lr_critic: float = 1e-3, gamma: float = 0.95, tau: float = 0.01, device="cuda", act_dtype=None):
+                 lr_critic: float = 1e-3, gamma: float = 0.95, tau: float = 0.01, device="cuda", act_dtype=None,
+                 data_parallel: bool = False, group=None):
         mk = lambda i, o, c: MLPNetwork(i, o, hidden_dim, c).to(device)
         self.policy, self.target_policy = mk(obs_dim, act_dim, True), mk(obs_dim, act_dim, True)
         self.critic, self.target_critic = mk(obs_dim + act_dim, 1, False), mk(obs_dim + act_dim, 1, False)
+        self.group = group
+        self.data_parallel = bool(data_parallel) and dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(group) > 1
+        if data_parallel and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("data_parallel=True needs torch.distributed.init_process_group() first")
+        if self.data_parallel:
+            for net in (self.policy, self.critic):                         # one message per network
+                flat = torch.cat([p.data.reshape(-1) for p in net.parameters()])
+                if dist.get_rank(group) != 0:                              # SUM of (rank 0's weights, zeros, ...) = a broadcast
+                    flat.zero_()
+                all_reduce_sum(flat, group)
+                off = 0
+                for p in net.parameters():
+                    p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
         self.target_policy.load_state_dict(self.policy.state_dict())       # agents.py:39-40
         self.target_critic.load_state_dict(self.critic.state_dict())
         self.policy_optimizer = torch.optim.Adam(self.policy.parameters(), lr_actor)
         self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr_critic)
+        self._pol_grads = _FlatGrads(self.policy) if self.data_parallel else None
+        self._cri_grads = _FlatGrads(self.critic) if self.data_parallel else None
         self.gamma, self.tau = gamma, tau
         self.act_dtype = act_dtype                                         # rollout inference precision; None = float32
         self.niter = 0
@@ -57,8 +101,9 @@ class DDPGLearner:
     def act(self, obs: torch.Tensor, out: torch.Tensor, noise_scale: float = 0.0, epsilon: float = 0.0,
             generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """agents.py:69-96 for a batch of environments: obs (E, obs_dim, n_a) -> out (E, 2, n_a).
-        With probability epsilon the whole step is uniform random, else Gaussian noise is added and
-        the action clamped to [-1, 1]."""
+        Per environment (the reference draws its coin once per step of its one environment, agents.py:87):
+        with probability epsilon the whole team acts uniformly at random, else Gaussian noise is added and the
+        action clamped to [-1, 1].  generator: a torch.Generator on the environment's device."""
         E, d, n = obs.shape
         x = obs.transpose(1, 2).reshape(E * n, d)                          # maddpg.py:84: observations.t()
         if self.act_dtype is not None:                                     # e.g. torch.bfloat16: MFMA inference for rollouts
@@ -66,40 +111,59 @@ class DDPGLearner:
                 a = self.policy(x).float()
         else:
             a = self.policy(x)
-        if epsilon > 0.0 and torch.rand((), generator=generator, device="cpu").item() < epsilon:
-            a = torch.empty_like(a).uniform_(-1.0, 1.0, generator=generator)
-        elif noise_scale > 0.0:
+        a = a.view(E, n, -1)
+        if noise_scale > 0.0:                                              # agents.py:91-94
             a = (a + noise_scale * torch.randn(a.shape, device=a.device, generator=generator)).clamp_(-1.0, 1.0)
-        out.copy_(a.view(E, n, -1).transpose(1, 2))
+        if epsilon > 0.0:                                                  # agents.py:87-89, one coin per environment
+            coin = torch.rand(E, 1, 1, device=a.device, generator=generator) < epsilon
+            a = torch.where(coin, torch.empty_like(a).uniform_(-1.0, 1.0, generator=generator), a)
+        out.copy_(a.transpose(1, 2))
         return out
 
-    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5):
-        """maddpg.py:99-190."""
-        self.critic_optimizer.zero_grad()
-        with torch.no_grad():
+    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True):
+        """maddpg.py:99-190.  Returns (critic loss, policy loss): Python floats, or 0-d tensors when
+        sync_losses=False (no host synchronisation inside the update loop)."""
+        if self.data_parallel:
+            self._cri_grads.zero()
+        else:
+            self.critic_optimizer.zero_grad()                              # maddpg.py:120
+        with torch.no_grad():                                              # maddpg.py:123-127 (.detach() at :134)
             trgt_in = torch.cat((next_obs, self.target_policy(next_obs)), dim=1)
             target_value = rews + self.gamma * self.target_critic(trgt_in) * (1 - dones)
-        vf_loss = F.mse_loss(self.critic(torch.cat((obs, acs), dim=1)), target_value)
+        vf_loss = F.mse_loss(self.critic(torch.cat((obs, acs), dim=1)), target_value)   # maddpg.py:130-134
         vf_loss.backward()
+        if self.data_parallel:
+            self._cri_grads.average(self.group)                            # maddpg.py:138-139
         self.critic_optimizer.step()
 
-        self.policy_optimizer.zero_grad()
+        if self.data_parallel:
+            self._pol_grads.zero()
+        else:
+            self.policy_optimizer.zero_grad()                              # maddpg.py:144
         pol = self.policy(obs)
-        pol_loss = -self.critic(torch.cat((obs, pol), dim=1)).mean()
+        pol_loss = -self.critic(torch.cat((obs, pol), dim=1)).mean()       # maddpg.py:153-154
         if acs_prior is not None:                                          # maddpg.py:158-174
             valid = ~(acs_prior.abs() < 1e-2).all(dim=1)
-            if valid.any():
+            if self.data_parallel:                                         # no data-dependent branch: every rank runs the same ops
+                w = valid.to(pol.dtype).unsqueeze(1)
+                reg = ((pol - acs_prior) ** 2 * w).sum() / (w.sum() * pol.shape[1]).clamp_min(1.0)
+                pol_loss = pol_loss + 0.3 * alpha * reg
+            elif valid.any():
                 pol_loss = pol_loss + 0.3 * alpha * F.mse_loss(pol[valid], acs_prior[valid])
         pol_loss.backward()
+        if self.data_parallel:
+            self._pol_grads.average(self.group)                            # maddpg.py:179-180
         self.policy_optimizer.step()
-        return float(vf_loss.detach()), float(pol_loss.detach())
+        if sync_losses:
+            return float(vf_loss.detach()), float(pol_loss.detach())
+        return vf_loss.detach(), pol_loss.detach()
 
     @torch.no_grad()
     def update_all_targets(self):
-        """maddpg.py:192-199 (soft update, misc.py)."""
+        """maddpg.py:192-199 with the soft update of misc.py:9-19: target * (1 - tau) + source * tau."""
         for tgt, src in ((self.target_critic, self.critic), (self.target_policy, self.policy)):
             for tp, p in zip(tgt.parameters(), src.parameters()):
-                tp.mul_(1.0 - self.tau).add_(p, alpha=self.tau)
+                tp.copy_(tp * (1.0 - self.tau) + p * self.tau)
         self.niter += 1
 
 
@@ -157,13 +221,17 @@ def collect_expert_episode(env: BatchedAssemblyEnv, replay: DeviceReplay, episod
 
 def train_phase(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceReplay, batch_size: int = 2048,
                 num_updates: Optional[int] = None):
-    """train_assembly.py:141-157."""
+    """train_assembly.py:141-157.  Returns the (critic loss, policy loss) pairs as floats; the losses are read
+    back once, after the last update, so the loop itself never waits for the device."""
     if num_updates is None:
         num_updates = 30 if batch_size >= 2048 else 20
     losses = []
     for _ in range(num_updates):
         if len(replay) >= batch_size:
             obs, acs, rews, nxt, dones, prior = replay.sample(batch_size, is_prior=env.training_method == "llm_rl")
-            losses.append(learner.update(obs, acs, rews, nxt, dones, prior, env.alpha))
+            losses.append(learner.update(obs, acs, rews, nxt, dones, prior, env.alpha, sync_losses=False))
         learner.update_all_targets()
+    if losses:
+        flat = torch.stack([torch.stack(pair) for pair in losses]).cpu().tolist()
+        losses = [(v, p) for v, p in flat]
     return losses

@@ -28,12 +28,25 @@ def split_range(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
     return first, base + (1 if rank < rem else 0)
 
 
+def all_reduce_sum(t: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """SUM all-reduce of t in place.  RCCL reduces the device tensor where it lies; under gloo (CPU tests, and
+    rehearsals of the multi-rank control flow with several ranks on one GPU) a device tensor goes through the
+    host, because gloo's own device-tensor path stalls when ranks share a busy GPU."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def reduce_episode_stats(local_stats: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Sum the per-rank [8] float64 vector over all ranks (in place) and return it."""
     if local_stats.shape != (8,) or local_stats.dtype != torch.float64:
         raise ValueError("episode statistics are 8 float64 values")
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(local_stats, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_sum(local_stats, group)
     return local_stats
 
 

@@ -56,6 +56,23 @@ def test_reset_draw_order_matches_reference_ranges():
     assert np.abs(e.p).max() <= 2.4 and np.abs(e.dp).max() <= 0.5 and e.n_g in (497, 487, 534, 516, 510, 502, 536)
 
 
+def test_seeded_reset_reproduces_the_reference_initial_state():
+    """np.random.seed(226) -> build -> reset() draws shape, rotation, offset, positions and velocities from numpy's
+    global stream in the reference's order (assembly.py:151-218): the state equals the one the reference
+    environment reached from the same seed (recorded in rollout_n30_seed226.npz by make_golden.py)."""
+    import marl_amd.gym as gym
+    from marl_amd.gym.wrappers import AssemblySwarmWrapper
+    from marl_amd.cfg import AssemblyArgs
+    z = np.load(os.path.join(GOLDEN, "rollout_n30_seed226.npz"))
+    np.random.seed(226)
+    env = AssemblySwarmWrapper(gym.make("AssemblySwarm-v0").unwrapped, AssemblyArgs(n_a=30))
+    obs = env.reset()
+    e = env.env
+    assert np.array_equal(e.p, z["p0"]) and np.array_equal(e.dp, z["dp0"])
+    assert np.array_equal(e.grid_center, z["grid"]) and e.l_cell == float(z["l_cell"]) and e.n_g == z["grid"].shape[1]
+    assert np.array_equal(obs, z["obs0"]) and np.array_equal(e.neighbor_index, z["nbr0"])
+
+
 @pytest.mark.parametrize("name", ["rule", "llm"])
 def test_in_environment_policies_follow_the_reference(name):
     """agent_strategy 'rule' / 'llm' (assembly.py:520-596): the environment steps itself; the recorded

@@ -68,6 +68,22 @@ def test_shapes_match_reference_table():
     assert l_cell == pytest.approx(2.2 / 5)
 
 
+REF_FIG = "/root/reference/fig"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_FIG), reason="needs the reference's fig/*.png (only in the build container)")
+def test_packaged_grids_equal_the_pipeline_on_the_reference_images():
+    """marl_amd/data/shapes.npz is exactly what the PNG pipeline (assembly_cfg.py:47-102 restated in
+    marl_amd/shapes.py) yields on the reference's seven images."""
+    from marl_amd.shapes import grid_from_png, load_shapes, sorted_pngs
+    l_cells, grids = load_shapes()
+    paths = sorted_pngs(REF_FIG)
+    assert [os.path.basename(p) for p in paths] == ["1.png", "3.png", "4.png", "5.png", "6.png", "7.png", "8.png"]
+    for k, path in enumerate(paths):
+        l_cell, grid = grid_from_png(path)
+        assert l_cell == l_cells[k] and np.array_equal(grid, grids[k]), path
+
+
 def test_gym_shim_semantics():
     import marl_amd.gym as gym
     from marl_amd.gym.core import TimeLimit
