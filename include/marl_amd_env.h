@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ASM_ABI_VERSION 1
+#define ASM_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ (A) -- */
 
@@ -128,6 +128,59 @@ const char *asm_last_error(void);
 int asm_device_count(void);
 
 /*
+ * Target-grid bitmap.  Every shape the reference derives from an image is a subset of a regular lattice: cells
+ * are the all-black 36-pixel tiles, listed row by row (assembly_cfg.py:60-80), so cell index order is
+ * (lattice row, lattice column) order.  asm_lattice_shape holds that lattice for one shape: per lattice row the
+ * occupied columns as bit windows with the index of the first cell at or after the window start, and the list of
+ * boundary cells (cells with a missing 4-neighbour: the only cells, besides the four lattice sites around a query
+ * point, that can be nearest to it).  Given it, and per environment the shape id and the rigid transform the reset
+ * applied (assembly.py:170-182), the step kernel finds an agent's sensed cells by enumerating the lattice rows its
+ * sensing disc crosses (each row contributes one contiguous run of cell indices) instead of testing every cell,
+ * and its nearest cell among boundary cells + 4 sites.  Every decision stays the reference's: anything within
+ * rounding distance of a threshold is re-evaluated in double on the stored cell coordinates.
+ *
+ * The description is a promise by the caller: grid[e] must hold, rounded to float, the cells of shape
+ * shape_id[e] transformed by xform[e]:  x = c*gx + s*gy + ox,  y = -s*gx + c*gy + oy  (c, s, ox, oy = xform[e][0..3]).
+ * asm_batch_reset_f32 produces exactly that when given xform / shape_id outputs.  Pass lattice = NULL whenever the
+ * grid arrays were written any other way.
+ */
+#define ASM_LAT_ROWS   48    /* table rows: lattice rows + one empty row below and above (rows <= 46) */
+#define ASM_LAT_CHUNKS 3     /* 32-bit column windows per row, starting at columns 0, 16, 32 (columns <= 48) */
+#define ASM_LAT_NB     256   /* boundary-list capacity */
+
+typedef struct asm_lattice_shape {
+    uint32_t row_tab[ASM_LAT_ROWS][ASM_LAT_CHUNKS][2];  /* [row + 1][j] = { occupancy bits of columns 16j .. 16j+31,
+                                                           index of the first cell of the row at a column >= 16j } */
+    uint16_t boundary[ASM_LAT_NB];                      /* boundary cell indices, ascending */
+    int32_t n_boundary, cols, rows, n_g;
+    double x0, y0;                                      /* canonical coordinates of lattice site (column 0, row 0) */
+    double l_cell;                                      /* lattice pitch */
+    double reserved;
+} asm_lattice_shape;
+
+/* Host-side: fills *out from the canonical cell centres grid_xy[n_g][2] (the 'grid_coords' entry of results.pkl,
+ * assembly.py:115) and the cell size.  Returns 0, or non-zero with asm_last_error() set when the cells are not a
+ * row-major subset of a lattice of pitch l_cell or exceed the table sizes above (then run without a lattice). */
+int asm_lattice_build(const double *grid_xy, int n_g, double l_cell, asm_lattice_shape *out);
+
+typedef struct asm_lattice {
+    const asm_lattice_shape *shapes;   /* device memory, n_shapes entries */
+    int32_t n_shapes;
+    int32_t reserved;
+    const int32_t *shape_id;           /* device [E]     shape of every environment */
+    const double *xform;               /* device [E][4]  cos, sin, offset x, offset y of every environment */
+    double l_cell_min;                 /* smallest l_cell among the shapes (host value; the kernels' lattice window
+                                          covers d_sen <= 7.4 l_cell_min and r_avoid/2 <= 3.4 l_cell_min; beyond
+                                          that the calls run as if lattice were NULL) */
+} asm_lattice;
+
+/* Number of cells of grid[e] that differ from the lattice description by more than tol, summed over the E
+ * environments, written to *n_bad (one device int32, zeroed by this call's kernel).  A debugging aid for callers
+ * that maintain grid / shape_id / xform themselves. */
+int asm_batch_check_lattice(const asm_params *prm, int E, const float *grid, const int32_t *n_g,
+                            const asm_lattice *lattice, double tol, int32_t *n_bad, void *stream);
+
+/*
  * Array layouts (all contiguous, device memory, E environments):
  *   p, dp, act, a_prior  [E][2][n_a]        float   (component-major, as ENV's (2, n_a))
  *   grid                 [E][2][n_g_max]    float   (ENV's grid_center (2, n_g), padded)
@@ -156,7 +209,7 @@ int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const fl
                           const float *grid, const int32_t *n_g, const double *l_cell,
                           int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
                           float *obs, float *reward /*nullable*/, int32_t *sensed_index /*nullable*/,
-                          int32_t *occupied_index /*nullable*/, void *stream);
+                          int32_t *occupied_index /*nullable*/, const asm_lattice *lattice /*nullable*/, void *stream);
 
 /*
  * One full step, ENV:482-661 with agent_strategy 'input', for E environments.
@@ -174,7 +227,8 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
                        int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
                        float *obs, float *reward, float *a_prior /*nullable*/,
                        int32_t *sensed_index /*nullable*/, int32_t *occupied_index /*nullable*/,
-                       double *stats /*nullable*/, int recompute_target, void *stream);
+                       double *stats /*nullable*/, int recompute_target, const asm_lattice *lattice /*nullable*/,
+                       void *stream);
 
 /*
  * Batched reset, ENV:151-218: per environment a shape, a rotation, an offset and
@@ -184,8 +238,8 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
  * Shapes: n_shapes canonical grids; grid k has shape_ng[k] cells stored as
  * (x, y) rows starting at shape_grids + 2*shape_off[k] (the 'grid_coords' layout
  * ENV:115 loads), cell size shape_lcell[k] — all device memory, doubles / int32.
- * Writes shape_id, p, dp, grid, n_g, l_cell; then the observation of the new
- * state exactly as asm_batch_observe_f32 (reward is not produced, ENV:216-218).
+ * Writes shape_id, p, dp, grid, n_g, l_cell (and, if given, the rotation and offset it drew as xform); then
+ * the observation of the new state exactly as asm_batch_observe_f32 (reward is not produced, ENV:216-218).
  */
 int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, int64_t env0, int E,
                         int n_shapes, const double *shape_grids, const int32_t *shape_off,
@@ -193,7 +247,9 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
                         float *p, float *dp, float *grid, int32_t *n_g, double *l_cell,
                         int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell,
                         float *obs, int32_t *sensed_index /*nullable*/,
-                        int32_t *occupied_index /*nullable*/, void *stream);
+                        int32_t *occupied_index /*nullable*/, double *xform /*nullable: [E][4] cos, sin, offset x, y */,
+                        const asm_lattice *lattice /*nullable; its shape_id / xform must be the arrays written here */,
+                        void *stream);
 
 /* U(-1,1) float32 actions from the same generator (ENV:519 'random' strategy):
  * act[e][c][i] = draw (seed, env0+e, counter stream 1, step, c*n_a+i). */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MARL_AMD_LIB: load another build of the same library (e.g. the diagnostic build of `make diag`)
 SO_PATH = os.environ.get("MARL_AMD_LIB") or os.path.join(_HERE, "csrc", "build", "libAssemblyEnv.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AsmParams(C.Structure):
@@ -25,12 +25,29 @@ class AsmParams(C.Structure):
                 ("sensitivity", C.c_double), ("mass", C.c_double), ("half_w", C.c_double), ("half_h", C.c_double)]
 
 
+LAT_ROWS, LAT_CHUNKS, LAT_NB = 48, 3, 256
+
+
+class AsmLatticeShape(C.Structure):
+    """struct asm_lattice_shape of include/marl_amd_env.h."""
+    _fields_ = [("row_tab", C.c_uint32 * 2 * LAT_CHUNKS * LAT_ROWS), ("boundary", C.c_uint16 * LAT_NB),
+                ("n_boundary", C.c_int32), ("cols", C.c_int32), ("rows", C.c_int32), ("n_g", C.c_int32),
+                ("x0", C.c_double), ("y0", C.c_double), ("l_cell", C.c_double), ("reserved", C.c_double)]
+
+
+class AsmLattice(C.Structure):
+    """struct asm_lattice of include/marl_amd_env.h (device pointers as integers)."""
+    _fields_ = [("shapes", C.c_void_p), ("n_shapes", C.c_int32), ("reserved", C.c_int32), ("shape_id", C.c_void_p),
+                ("xform", C.c_void_p), ("l_cell_min", C.c_double)]
+
+
 # Every symbol include/marl_amd_env.h declares.
 EXPORTS = ["_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
            "asm_default_params", "asm_obs_dim", "asm_abi_version", "asm_last_error", "asm_device_count",
            "asm_batch_observe_f32", "asm_batch_step_f32", "asm_batch_reset_f32",
            "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_batch_rule_actions_f32", "asm_replay_gather_f32", "asm_replay_draw_indices",
-           "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err", "asm_get_observation_noalloc"]
+           "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err", "asm_get_observation_noalloc", "asm_lattice_build",
+           "asm_batch_check_lattice"]
 
 _lib = None
 
@@ -59,11 +76,16 @@ def load() -> C.CDLL:
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
     PP = C.POINTER(AsmParams)
     lib.asm_batch_observe_f32.restype = C.c_int
-    lib.asm_batch_observe_f32.argtypes = [PP, i32] + [vp] * 12 + [vp]
+    LP = C.POINTER(AsmLattice)
+    lib.asm_batch_observe_f32.argtypes = [PP, i32] + [vp] * 12 + [LP, vp]
     lib.asm_batch_step_f32.restype = C.c_int
-    lib.asm_batch_step_f32.argtypes = [PP, i32] + [vp] * 15 + [i32, vp]
+    lib.asm_batch_step_f32.argtypes = [PP, i32] + [vp] * 15 + [i32, LP, vp]
     lib.asm_batch_reset_f32.restype = C.c_int
-    lib.asm_batch_reset_f32.argtypes = [PP, u64, u32, i64, i32, i32] + [vp] * 16 + [vp]
+    lib.asm_batch_reset_f32.argtypes = [PP, u64, u32, i64, i32, i32] + [vp] * 16 + [vp, LP, vp]
+    lib.asm_lattice_build.restype = C.c_int
+    lib.asm_lattice_build.argtypes = [vp, i32, C.c_double, C.POINTER(AsmLatticeShape)]
+    lib.asm_batch_check_lattice.restype = C.c_int
+    lib.asm_batch_check_lattice.argtypes = [PP, i32, vp, vp, LP, C.c_double, vp, vp]
     lib.asm_batch_random_actions_f32.restype = C.c_int
     lib.asm_batch_random_actions_f32.argtypes = [u64, u32, i64, i32, i32, vp, vp]
     lib.asm_batch_rule_actions_f32.restype = C.c_int

@@ -12,6 +12,7 @@ done (E, 1, n_a) all False, a_prior (E, 2, n_a).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import Optional, Sequence
 
@@ -36,7 +37,7 @@ class BatchedAssemblyEnv:
                  is_boundary: bool = True, is_con_self_state: bool = True, training_method: str = "llm_rl",
                  shapes=None, r_avoid: Optional[float] = None, d_sen: float = 0.4, n_g_max: Optional[int] = None,
                  keep_indices=False, keep_stats: bool = True, num_obs_grid_max: int = 80,
-                 num_occupied_grid_max: int = 200):
+                 num_occupied_grid_max: int = 200, use_lattice: bool = True):
         self.lib = _lib.load()
         self.E = int(num_envs)
         self.n_a = int(n_a)
@@ -100,9 +101,46 @@ class BatchedAssemblyEnv:
         self._shape_lcell = torch.tensor(self.l_cells, dtype=torch.float64, device=dev)
         self._recompute_target = False
         self._step_sig, self._step_args = None, None
+        # The shapes' lattice description (include/marl_amd_env.h, asm_lattice): lets the step kernel enumerate lattice
+        # rows instead of testing every cell.  It describes grids produced by reset() / set_shape(); it is switched
+        # off until the first of those, and by invalidate_lattice() (call it after writing grid_center directly).
+        self.xform = torch.zeros(E, 4, dtype=torch.float64, device=dev)
+        self._lattice, self._lattice_shapes, self.lattice_valid = None, None, False
+        if use_lattice and os.environ.get("MARL_AMD_NO_LATTICE") != "1":     # the variable: A/B measurements of one build
+            self._build_lattice()
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
 
     # ------------------------------------------------------------------
+    def _build_lattice(self) -> None:
+        arr = (_lib.AsmLatticeShape * self.num_train_shape)()
+        for k, g in enumerate(self.grid_center_origins):
+            xy = np.ascontiguousarray(g, dtype=np.float64)
+            if self.lib.asm_lattice_build(xy.ctypes.data, xy.shape[0], float(self.l_cells[k]), C.byref(arr[k])) != 0:
+                return                                          # not a lattice (custom shapes): every cell is tested
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self._lattice_shapes = torch.from_numpy(raw).to(self.device)
+        self._lattice = _lib.AsmLattice(self._lattice_shapes.data_ptr(), self.num_train_shape, 0, self.shape_id.data_ptr(),
+                                        self.xform.data_ptr(), float(min(self.l_cells)))
+
+    def _lat(self):
+        return C.byref(self._lattice) if (self._lattice is not None and self.lattice_valid) else None
+
+    def invalidate_lattice(self) -> None:
+        """Call after writing grid_center / n_g / shape_id / xform directly: the kernels then test every cell against
+        every agent (the grids no longer follow the lattice description) until the next reset() or set_shape()."""
+        self.lattice_valid = False
+
+    def check_lattice(self, tol: float = 1e-6) -> int:
+        """Cells of grid_center that are not where the lattice description says (0 when it is valid); synchronises."""
+        if self._lattice is None:
+            raise RuntimeError("no lattice description (use_lattice=False or the shapes are not lattices)")
+        n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.asm_batch_check_lattice(C.byref(self.params), self.E, _ptr(self.grid_center), _ptr(self.n_g),
+                                                  C.byref(self._lattice), float(tol), _ptr(n_bad), self._stream())
+        _lib.check(rc, "asm_batch_check_lattice")
+        return int(n_bad.item())
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -116,8 +154,10 @@ class BatchedAssemblyEnv:
                 _ptr(self._shape_grids), _ptr(self._shape_off), _ptr(self._shape_ng), _ptr(self._shape_lcell),
                 _ptr(self.shape_id), _ptr(self.p), _ptr(self.dp), _ptr(self.grid_center), _ptr(self.n_g),
                 _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags), _ptr(self.nearest_cell),
-                _ptr(self.obs), _ptr(self.sensed_index), _ptr(self.occupied_index), self._stream())
+                _ptr(self.obs), _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.xform),
+                None if self._lattice is None else C.byref(self._lattice), self._stream())
         _lib.check(rc, "asm_batch_reset_f32")
+        self.lattice_valid = self._lattice is not None
         if self.stats is not None:
             self.stats.zero_()
         self._recompute_target = False
@@ -131,7 +171,7 @@ class BatchedAssemblyEnv:
                 C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), _ptr(self.grid_center), _ptr(self.n_g),
                 _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags), _ptr(self.nearest_cell),
                 _ptr(self.obs), _ptr(self.reward) if want_reward else None, _ptr(self.sensed_index),
-                _ptr(self.occupied_index), self._stream())
+                _ptr(self.occupied_index), self._lat(), self._stream())
         _lib.check(rc, "asm_batch_observe_f32")
         self._recompute_target = False
         return self.obs
@@ -155,16 +195,19 @@ class BatchedAssemblyEnv:
         # is always honoured.
         sig = tuple(0 if t is None else t.data_ptr() for t in (
             self.obs, self.reward, prior, self.p, self.dp, self.grid_center, self.n_g, self.l_cell, self.neighbor_index,
-            self.in_flags, self.nearest_cell, self.sensed_index, self.occupied_index, self.stats))
+            self.in_flags, self.nearest_cell, self.sensed_index, self.occupied_index, self.stats, self.shape_id, self.xform))
         if self._step_sig != sig:
             self._step_sig = sig
             self._step_args = [C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), None, _ptr(self.grid_center),
                                _ptr(self.n_g), _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags),
                                _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior),
-                               _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.stats), 0, None]
+                               _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.stats), 0, None, None]
+            if self._lattice is not None:
+                self._lattice.shape_id, self._lattice.xform = self.shape_id.data_ptr(), self.xform.data_ptr()
         args = self._step_args
         args[4] = C.c_void_p(a.data_ptr()); args[17] = int(self._recompute_target)
-        args[18] = self._stream() if stream_ptr is None else C.c_void_p(stream_ptr)
+        args[18] = self._lat()
+        args[19] = self._stream() if stream_ptr is None else C.c_void_p(stream_ptr)
         if torch.cuda.current_device() == self._dev_index:
             rc = self.lib.asm_batch_step_f32(*args)
         else:
@@ -233,6 +276,9 @@ class BatchedAssemblyEnv:
         self.n_g[sel] = n_g
         self.l_cell[sel] = self.l_cells[k]
         self.shape_id[sel] = k
+        self.xform[sel] = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=self.device)   # unrotated, centred
+        if env_ids is None:                                     # every grid now follows the lattice description again
+            self.lattice_valid = self._lattice is not None
         self._recompute_target = True
 
     def episode_stats(self) -> torch.Tensor:

@@ -151,12 +151,38 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
             // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on, 64 own-position entries; masks; occupancy;
             // partials; flags; reward partials; slot lists (+ one emission round of padding) aliased with the word keys
             const size_t bytes = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
-                                 4 * 128 + 4 * 3 * 64 * (size_t)T + std::max(2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW);
+                                 4 * 128 + 4 * 3 * 64 * (size_t)T +
+                                 std::max({2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW,
+                                           (size_t)(4 * 4 * ASM_LAT_NB + 4 * 64 * (ASM_LAT_NB / 32))});   // lattice path: compact boundary coordinates + word keys
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
         }
     }
     *out = P;
     return 0;
+}
+
+// The lattice path of k_step_fast: decides whether this call may use it and fills the kernel's view of it.
+// Conditions: the 4-wave schedule with walls; the tables fit the unused part of the kernel's grid area in LDS;
+// the sensing disc fits the kernel's window of 15 lattice rows x 15 columns and the occupancy disc 7 x 7.
+bool lattice_usable(const asm_lattice *lat, const asm_params *prm, DevParams *P, asmenv::LatArgs *out)
+{
+    P->lat = 0;
+    if (!lat || !lat->shapes || !lat->shape_id || !lat->xform || lat->n_shapes < 1 || !(lat->l_cell_min > 0)) return false;
+    if (P->fast_T != 4 || P->periodic) return false;
+    const size_t table_floats = 2 * sizeof(uint32_t) * (ASM_LAT_ROWS * ASM_LAT_CHUNKS * 2) / 4 + 2 * sizeof(uint16_t) * ASM_LAT_NB / 4;
+    if (2 * (size_t)P->NGP + 64 + table_floats > ASM_GY_OFF) return false;
+    const double R = prm->d_sen / lat->l_cell_min, Ro = prm->r_avoid / 2.0 / lat->l_cell_min;
+    if (!(R <= 7.4) || !(Ro <= 3.4)) return false;
+    P->lat = 1;
+    P->lat_KO = (int)std::floor(Ro + 0.5 + 1e-9);                       // lattice rows |k| <= KO can hold an occupied cell
+    if (P->lat_KO < 1) P->lat_KO = 1;
+    // stored cell coordinates are floats of magnitude below half_w + half_h: half an ulp each; a squared lattice
+    // distance near the sensing radius moves by at most 2 sqrt(2) R times that (in lattice units); x 2.5 for safety
+    const double cmax = prm->half_w + prm->half_h;
+    const double half_ulp = std::ldexp(1.0, (int)std::ceil(std::log2(cmax)) - 24) / 2.0;
+    P->lat_cb = (float)(2.5 * 2.8284271247461903 * half_ulp);
+    out->shapes = lat->shapes; out->shape_id = lat->shape_id; out->xform = lat->xform; out->n_shapes = lat->n_shapes;
+    return true;
 }
 
 int hip_fail(int rc, const char *what)
@@ -234,6 +260,54 @@ void asm_default_params(asm_params *p, int n_a, int n_g_max)
     p->c_wall = 5; p->dt = 0.1; p->sensitivity = 1; p->mass = 1; p->half_w = 2.4; p->half_h = 2.4;
 }
 
+int asm_lattice_build(const double *grid_xy, int n_g, double l_cell, asm_lattice_shape *out)
+{
+    if (!grid_xy || !out || n_g < 1 || !(l_cell > 0)) return fail(1, "asm_lattice_build: bad arguments");
+    if (n_g > 1024) return fail(1, "asm_lattice_build: n_g = %d > 1024", n_g);
+    std::memset(out, 0, sizeof *out);
+    double xmin = grid_xy[0], ymin = grid_xy[1];
+    for (int c = 1; c < n_g; ++c) { xmin = std::min(xmin, grid_xy[2 * c]); ymin = std::min(ymin, grid_xy[2 * c + 1]); }
+    static thread_local int col[1024], row[1024];
+    int cols = 0, rows = 0;
+    for (int c = 0; c < n_g; ++c) {
+        const double u = (grid_xy[2 * c] - xmin) / l_cell, v = (grid_xy[2 * c + 1] - ymin) / l_cell;
+        const double ur = std::nearbyint(u), vr = std::nearbyint(v);
+        if (std::fabs(u - ur) > 1e-9 || std::fabs(v - vr) > 1e-9)
+            return fail(2, "asm_lattice_build: cell %d is not on a lattice of pitch %.17g", c, l_cell);
+        col[c] = (int)ur; row[c] = (int)vr;
+        cols = std::max(cols, col[c] + 1); rows = std::max(rows, row[c] + 1);
+        if (c > 0 && !(row[c] > row[c - 1] || (row[c] == row[c - 1] && col[c] > col[c - 1])))
+            return fail(2, "asm_lattice_build: cells %d, %d are not in row-major lattice order", c - 1, c);
+    }
+    if (cols > 16 * ASM_LAT_CHUNKS || rows > ASM_LAT_ROWS - 2)
+        return fail(3, "asm_lattice_build: %d x %d lattice exceeds %d columns x %d rows", cols, rows, 16 * ASM_LAT_CHUNKS, ASM_LAT_ROWS - 2);
+    static thread_local unsigned char occ[ASM_LAT_ROWS][64];
+    std::memset(occ, 0, sizeof occ);
+    for (int c = 0; c < n_g; ++c) occ[row[c] + 1][col[c]] = 1;
+    int c = 0;                                                          // cells before the current position
+    for (int r = 0; r < ASM_LAT_ROWS; ++r) {
+        int before[65]; before[0] = c;
+        for (int a = 0; a < 64; ++a) { c += occ[r][a]; before[a + 1] = c; }
+        for (int j = 0; j < ASM_LAT_CHUNKS; ++j) {
+            uint32_t bits = 0;
+            for (int b = 0; b < 32 && 16 * j + b < 64; ++b) bits |= (uint32_t)occ[r][16 * j + b] << b;
+            out->row_tab[r][j][0] = bits; out->row_tab[r][j][1] = (uint32_t)before[16 * j];
+        }
+    }
+    int nb = 0;
+    for (int k = 0; k < n_g; ++k) {
+        const int r = row[k] + 1, a = col[k];
+        const bool inner = occ[r - 1][a] && occ[r + 1][a] && (a > 0 && occ[r][a - 1]) && occ[r][a + 1];
+        if (!inner) {
+            if (nb >= ASM_LAT_NB) return fail(3, "asm_lattice_build: more than %d boundary cells", ASM_LAT_NB);
+            out->boundary[nb++] = (uint16_t)k;
+        }
+    }
+    out->n_boundary = nb; out->cols = cols; out->rows = rows; out->n_g = n_g;
+    out->x0 = xmin; out->y0 = ymin; out->l_cell = l_cell;
+    return 0;
+}
+
 int asm_obs_dim(const asm_params *p)
 {
     return 2 * 2 * (p->topo_nei_max + 1 + (p->is_con_self_state ? 1 : 0)) + 2 * p->num_obs_grid_max;
@@ -253,7 +327,7 @@ int asm_device_count(void)
 int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const float *dp, const float *grid,
                           const int32_t *n_g, const double *l_cell, int32_t *neighbor_index, int32_t *in_flags,
                           int32_t *nearest_cell, float *obs, float *reward, int32_t *sensed_index,
-                          int32_t *occupied_index, void *stream)
+                          int32_t *occupied_index, const asm_lattice *lattice, void *stream)
 {
     DevParams P;
     if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
@@ -263,7 +337,9 @@ int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const fl
     int rc;
     if (P.fast_T) {                                                 // the step kernel without its dynamics phase
         P.observe_only = 1; P.prior = 0;
-        rc = asmenv::launch_step_fast(P, const_cast<float *>(p), const_cast<float *>(dp), nullptr, grid, n_g, l_cell,
+        asmenv::LatArgs LA{};
+        lattice_usable(lattice, prm, &P, &LA);
+        rc = asmenv::launch_step_fast(P, LA, const_cast<float *>(p), const_cast<float *>(dp), nullptr, grid, n_g, l_cell,
                                       neighbor_index, in_flags, nearest_cell, obs, reward, nullptr, sensed_index,
                                       occupied_index, nullptr, (hipStream_t)stream);
     } else {
@@ -277,7 +353,8 @@ int asm_batch_observe_f32(const asm_params *prm, int E, const float *p, const fl
 int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const float *act, const float *grid,
                        const int32_t *n_g, const double *l_cell, int32_t *neighbor_index, int32_t *in_flags,
                        int32_t *nearest_cell, float *obs, float *reward, float *a_prior, int32_t *sensed_index,
-                       int32_t *occupied_index, double *stats, int recompute_target, void *stream)
+                       int32_t *occupied_index, double *stats, int recompute_target, const asm_lattice *lattice,
+                       void *stream)
 {
     DevParams P;
     if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
@@ -285,8 +362,10 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
         return fail(1, "asm_batch_step_f32: NULL required pointer");
     P.want_reward = 1; P.want_stats = stats != nullptr; P.recompute = recompute_target != 0;
     if (!a_prior) P.prior = 0;
+    asmenv::LatArgs LA{};
+    if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
     int rc = P.fast_T
-        ? asmenv::launch_step_fast(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
+        ? asmenv::launch_step_fast(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
                                    a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream)
         : asmenv::launch_step<float>(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
                                      reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
@@ -297,7 +376,8 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
                         const double *shape_grids, const int32_t *shape_off, const int32_t *shape_ng,
                         const double *shape_lcell, int32_t *shape_id, float *p, float *dp, float *grid, int32_t *n_g,
                         double *l_cell, int32_t *neighbor_index, int32_t *in_flags, int32_t *nearest_cell, float *obs,
-                        int32_t *sensed_index, int32_t *occupied_index, void *stream)
+                        int32_t *sensed_index, int32_t *occupied_index, double *xform, const asm_lattice *lattice,
+                        void *stream)
 {
     DevParams P;
     if (int rc = make_dev_params(prm, E, sizeof(float), &P)) return rc;
@@ -308,10 +388,14 @@ int asm_batch_reset_f32(const asm_params *prm, uint64_t seed, uint32_t episode, 
     P.state_only = P.fast_T != 0;                                   // then the step kernel observes the new state
     int rc = asmenv::launch_reset<float>(P, seed, episode, env0, n_shapes, shape_grids, shape_off, shape_ng,
                                          shape_lcell, shape_id, p, dp, grid, n_g, l_cell, neighbor_index, in_flags,
-                                         nearest_cell, obs, sensed_index, occupied_index, (hipStream_t)stream);
+                                         nearest_cell, obs, sensed_index, occupied_index, xform, (hipStream_t)stream);
     if (!rc && P.fast_T) {
         P.observe_only = 1; P.prior = 0; P.want_reward = 0; P.want_stats = 0;
-        rc = asmenv::launch_step_fast(P, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+        asmenv::LatArgs LA{};
+        if (lattice && (lattice->shape_id != shape_id || lattice->xform != xform || !xform))
+            return fail(1, "asm_batch_reset_f32: the lattice description must name the shape_id / xform arrays this call writes");
+        lattice_usable(lattice, prm, &P, &LA);
+        rc = asmenv::launch_step_fast(P, LA, p, dp, nullptr, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
                                       nullptr, nullptr, sensed_index, occupied_index, nullptr, (hipStream_t)stream);
     }
     return rc ? hip_fail(rc, "asm_batch_reset_f32") : 0;
@@ -365,6 +449,16 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
     int rc = asmenv::launch_replay_gather(E, n_a, obs_dim, episode_length, obs_ring, act_ring, prior_ring, rew_ring, index, N,
                                           obs_out, act_out, rew_out, next_obs_out, prior_out, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_replay_gather_f32") : 0;
+}
+
+int asm_batch_check_lattice(const asm_params *prm, int E, const float *grid, const int32_t *n_g,
+                            const asm_lattice *lattice, double tol, int32_t *n_bad, void *stream)
+{
+    if (!prm || E < 1 || !grid || !n_g || !lattice || !lattice->shapes || !lattice->shape_id || !lattice->xform || !n_bad)
+        return fail(1, "asm_batch_check_lattice: bad arguments");
+    asmenv::LatArgs LA{lattice->shapes, lattice->shape_id, lattice->xform, lattice->n_shapes};
+    int rc = asmenv::launch_check_lattice(E, prm->n_g_max, grid, n_g, LA, tol, n_bad, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_batch_check_lattice") : 0;
 }
 
 #ifdef ASM_DIAG

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/marl_amd_env.h"
+
 // k_step_fast keeps a cell's y this many floats after its x in LDS (x rows of the two environments first), a
 // compile-time distance (a multiple of 64) so that one address serves both; it must hold two rows of up to 1024 cells
 // and the 64 own-position entries that follow them.
@@ -30,6 +32,8 @@ struct DevParams {
     unsigned lds_env_bytes, lds_block_bytes;
     int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
     unsigned fast_lds_bytes;
+    int lat, lat_KO;                // k_step_fast lattice path: on/off; lattice rows |k| <= lat_KO can hold an occupied cell
+    float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)
     double T_sen;                   // norm < d_sen            CPP:663, 907
     double T_half_le;               // !(norm > r_avoid/2)     CPP:190
     double T_half_lt;               // norm < r_avoid/2        WRAP:67
@@ -39,6 +43,14 @@ struct DevParams {
     // single-precision screens (S = float): threshold, margins, inflated thresholds
     float Tsen_f, Tsen_amb_f, Tsen_hi_f, Thalf_hi_f, Thalf_f, Thalf_amb_f, Tcontact_hi_f, inv2dsen_f;
     double d_sen, r_avoid, sizes2, size_a, vel_max, k_ball, k_wall, c_wall, dt, sens, mass, half_w, half_h;
+};
+
+// The kernels' view of an asm_lattice (device pointers only).
+struct LatArgs {
+    const asm_lattice_shape *shapes;
+    const int *shape_id;
+    const double *xform;
+    int n_shapes;
 };
 
 template <typename S>
@@ -53,8 +65,10 @@ template <typename S>
 int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
                  const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,
                  int *shape_id, S *p, S *dp, S *grid, int *n_g, double *l_cell, int *nbr, int *inflags, int *nearest,
-                 S *obs, int *sensed, int *occupied, hipStream_t st);
-int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, const float *grid, const int *n_g,
+                 S *obs, int *sensed, int *occupied, double *xform, hipStream_t st);
+int launch_check_lattice(int E, int n_g_max, const float *grid, const int *n_g, const LatArgs &lat, double tol, int *n_bad,
+                         hipStream_t st);
+int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid, const int *n_g,
                      const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
                      int *sensed, int *occupied, double *stats, hipStream_t st);
 int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st);

@@ -58,6 +58,7 @@ __device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double
 
 #include "kernels_common.h"
 #include "kernels_generic.h"
+#include "kernels_lattice.h"
 #include "kernels_fast.h"
 #include "kernels_aux.h"
 #include "kernels_compat.h"
@@ -90,22 +91,25 @@ int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading
 }
 
 template <int T, bool PER>
-static int launch_step_fast_t(const DevParams &P, float *p, float *dp, const float *act, const float *grid,
+static int launch_step_fast_t(const DevParams &P, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid,
                               const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs,
                               float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
 {
     // three instantiations: the index-list outputs are compiled in only where they are asked for
     auto go = [&](auto kernel) {
         if (int rc = set_lds(kernel, P.fast_lds_bytes)) return rc;
-        hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, p, dp, act, grid, n_g,
+        hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, lat, p, dp, act, grid, n_g,
                            l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
         LAUNCH_CHECK();
         return 0;
     };
-    return occupied ? go(k_step_fast<T, PER, 2>) : sensed ? go(k_step_fast<T, PER, 1>) : go(k_step_fast<T, PER, 0>);
+    if constexpr (T == 4 && !PER)                                   // the lattice path exists for this schedule only
+        if (P.lat)
+            return occupied ? go(k_step_fast<T, PER, 2, true>) : sensed ? go(k_step_fast<T, PER, 1, true>) : go(k_step_fast<T, PER, 0, true>);
+    return occupied ? go(k_step_fast<T, PER, 2, false>) : sensed ? go(k_step_fast<T, PER, 1, false>) : go(k_step_fast<T, PER, 0, false>);
 }
 
-int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, const float *grid, const int *n_g,
+int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid, const int *n_g,
                      const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
                      int *sensed, int *occupied, double *stats, hipStream_t st)
 {
@@ -114,11 +118,11 @@ int launch_step_fast(const DevParams &P, float *p, float *dp, const float *act, 
       if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
 #endif
     if (P.periodic)                                                 // the host offers the periodic arena at T = 4 only
-        return launch_step_fast_t<4, true>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+        return launch_step_fast_t<4, true>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
     switch (P.fast_T) {
-    case 1: return launch_step_fast_t<1, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
-    case 2: return launch_step_fast_t<2, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
-    default: return launch_step_fast_t<4, false>(P, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    case 1: return launch_step_fast_t<1, false>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    case 2: return launch_step_fast_t<2, false>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
+    default: return launch_step_fast_t<4, false>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
     }
 }
 
@@ -138,12 +142,12 @@ template <typename S>
 int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
                  const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,
                  int *shape_id, S *p, S *dp, S *grid, int *n_g, double *l_cell, int *nbr, int *inflags, int *nearest,
-                 S *obs, int *sensed, int *occupied, hipStream_t st)
+                 S *obs, int *sensed, int *occupied, double *xform, hipStream_t st)
 {
     if (int rc = set_lds(k_reset<S>, P.lds_block_bytes)) return rc;
     hipLaunchKernelGGL(k_reset<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, seed, episode, env0,
                        n_shapes, shape_grids, shape_off, shape_ng, shape_lcell, shape_id, p, dp, grid, n_g, l_cell, nbr,
-                       inflags, nearest, obs, sensed, occupied);
+                       inflags, nearest, obs, sensed, occupied, xform);
     LAUNCH_CHECK();
     return 0;
 }
@@ -159,7 +163,17 @@ template int launch_step<float>(const DevParams &, float *, float *, const float
                                 hipStream_t);
 template int launch_reset<float>(const DevParams &, uint64_t, uint32_t, int64_t, int, const double *, const int *,
                                  const int *, const double *, int *, float *, float *, float *, int *, double *, int *,
-                                 int *, int *, float *, int *, int *, hipStream_t);
+                                 int *, int *, float *, int *, int *, double *, hipStream_t);
+
+int launch_check_lattice(int E, int n_g_max, const float *grid, const int *n_g, const LatArgs &lat, double tol, int *n_bad,
+                         hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(n_bad, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_check_lattice, dim3((unsigned)E), dim3(64), 0, st, E, n_g_max, grid, n_g, lat, tol, n_bad);
+    LAUNCH_CHECK();
+    return 0;
+}
 
 int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st)
 {

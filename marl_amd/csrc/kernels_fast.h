@@ -89,9 +89,10 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
-template <int T, bool PER, int IDX>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
-                                      // lists written (0 none, 1 sensed_index if given, 2 occupied_index too)
-__global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, float *p_g, float *dp_g, const float *act_g,
+template <int T, bool PER, int IDX, bool LAT>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
+                                      // lists written (0 none, 1 sensed_index if given, 2 occupied_index too); LAT: the agent x
+                                      // cell work runs on the shapes' lattice description (kernels_lattice.h; T = 4 only)
+__global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, LatArgs lat, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
                                                       float *rew_g, float *prior_g, int *sensed_g, int *occup_g,
@@ -123,6 +124,27 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int ng0 = e0 < P.E ? clamp_ng(ng_g[e0], P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng_g[e0 + 1], P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    // lattice path: the two environments' shape tables (row windows + boundary list, 1664 bytes each) go into the unused
+    // part of the grid area, between the x rows and the y rows
+    static_assert(!LAT || T == 4, "the lattice path is scheduled for four waves");
+    constexpr int LAT_TAB_BYTES = 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS + 2 * ASM_LAT_NB, LAT_TAB_VEC = LAT_TAB_BYTES / 16;
+    unsigned char *lat_tabs = reinterpret_cast<unsigned char *>(L.g + 2 * NGP + 64);
+    [[maybe_unused]] int lat_cols = 0, lat_rows = 0, lat_nb0 = 0, lat_nb1 = 0;
+    [[maybe_unused]] double lat_x0 = 0, lat_y0 = 0, lat_invl = 1, xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
+    [[maybe_unused]] uint4 lat_tv = make_uint4(0, 0, 0, 0);
+    if constexpr (LAT) {
+        int sid0 = e0 < P.E ? lat.shape_id[e0] : 0, sid1 = e0 + 1 < P.E ? lat.shape_id[e0 + 1] : 0;
+        sid0 = sid0 < 0 ? 0 : (sid0 >= lat.n_shapes ? lat.n_shapes - 1 : sid0);
+        sid1 = sid1 < 0 ? 0 : (sid1 >= lat.n_shapes ? lat.n_shapes - 1 : sid1);
+        lat_nb0 = e0 < P.E ? lat.shapes[sid0].n_boundary : 0; lat_nb1 = e0 + 1 < P.E ? lat.shapes[sid1].n_boundary : 0;
+        const asm_lattice_shape *sh = lat.shapes + (es ? sid1 : sid0);
+        lat_cols = sh->cols; lat_rows = sh->rows; lat_x0 = sh->x0; lat_y0 = sh->y0; lat_invl = 1.0 / sh->l_cell;
+        if (env_ok) { xf_c = lat.xform[(size_t)e * 4]; xf_s = lat.xform[(size_t)e * 4 + 1]; xf_ox = lat.xform[(size_t)e * 4 + 2]; xf_oy = lat.xform[(size_t)e * 4 + 3]; }
+        if (tid < 2 * LAT_TAB_VEC) {
+            const int h = tid >= LAT_TAB_VEC ? 1 : 0;
+            lat_tv = reinterpret_cast<const uint4 *>(lat.shapes + (h ? sid1 : sid0))[tid - h * LAT_TAB_VEC];
+        }
+    }
     {
         float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
         if (sub == 0 && active) {
@@ -162,10 +184,32 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
         if (sub == 0) { L.px[l] = sa; L.py[l] = sb; L.vx[l] = sc; L.vy[l] = sd; }
+        if constexpr (LAT) {
+            if (tid < 2 * LAT_TAB_VEC) reinterpret_cast<uint4 *>(lat_tabs)[tid] = lat_tv;
+            for (int w = tid; w < 64 * MW; w += 64 * T) L.mask[w] = 0;   // the sensed masks are built by OR-ing runs of cells
+        }
     }
     __syncthreads();
     STAMP(1);
     EXIT_AT(1);
+    // lattice path: the boundary cells' coordinates, compacted (the candidates of the nearest-cell pass).  Waves 2 and 3
+    // gather them, one environment each, while waves 0 and 1 run the dynamics; the next barrier publishes them.
+    [[maybe_unused]] float *lat_cbx = reinterpret_cast<float *>(L.sel), *lat_cby = lat_cbx + 2 * ASM_LAT_NB;   // [2][NB] each, aliasing the slot lists
+    [[maybe_unused]] unsigned *lat_wkey = reinterpret_cast<unsigned *>(lat_cby + 2 * ASM_LAT_NB);            // [64][NB / 32]
+    if constexpr (LAT) {
+        if (sub >= 2) {
+            const int h = sub - 2, nbh = h ? lat_nb1 : lat_nb0;
+            const unsigned short *bl = reinterpret_cast<const unsigned short *>(lat_tabs + h * LAT_TAB_BYTES + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
+            const float *gxh = L.g + (size_t)h * NGP;
+#pragma unroll
+            for (int k = l; k < ASM_LAT_NB; k += 64) {
+                float x = 1e30f, y = 1e30f;
+                if (k < nbh) { const int c = bl[k]; x = gxh[c]; y = gxh[c + ASM_GY_OFF]; }
+                lat_cbx[h * ASM_LAT_NB + k] = x; lat_cby[h * ASM_LAT_NB + k] = y;
+            }
+        }
+        if (P.observe_only) __syncthreads();                        // otherwise the barriers of the dynamics phase follow
+    }
 
     int contacts = 0;
     if (!P.observe_only) {                                          // reset / observe: the state is taken as it is
@@ -381,7 +425,82 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
     }
     STAMP(4);
-    {
+    if constexpr (LAT) {
+        // Lattice path (kernels_lattice.h).  Wave 0 has the k-NN pass above; waves 1..3 share the 15 lattice rows the
+        // sensing disc can cross (5 each) and the words of the compacted boundary list (nearest-cell screen); wave 3
+        // also evaluates the four lattice sites around the agent exactly.
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0;
+        if (sub != 0) {
+            LatLane A;
+            {
+                const double rxp = px - xf_ox, ryp = py - xf_oy;                        // inverse of assembly.py:172-173, 182
+                const double cxl = xf_c * rxp - xf_s * ryp, cyl = xf_s * rxp + xf_c * ryp;
+                double ud = (cxl - lat_x0) * lat_invl, vd = (cyl - lat_y0) * lat_invl;  // lattice units
+                ud = fmin(fmax(ud, -1000.0), 1000.0); vd = fmin(fmax(vd, -1000.0), 1000.0);   // unused lanes sit at -1e30
+                const double ur = rint(ud), vr = rint(vd);
+                A.ub = (int)ur; A.vb = (int)vr; A.fu = (float)(ud - ur); A.fv = (float)(vd - vr);
+                A.inr = active && A.ub >= -7 && A.ub <= lat_cols + 6 && A.vb >= -7 && A.vb <= lat_rows + 6;
+                const double Rd = P.d_sen * lat_invl, Rod = P.r_avoid * 0.5 * lat_invl;
+                const float invl_f = (float)lat_invl;
+                A.R2 = (float)(Rd * Rd); A.Ro2 = (float)(Rod * Rod);
+                A.band = P.lat_cb * (float)Rd * invl_f + 4e-6f * A.R2;
+                A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
+            }
+            const unsigned char *tab = lat_tabs + es * LAT_TAB_BYTES;
+            unsigned *mrow = L.mask + (size_t)l * MW;
+            unsigned und = 0;                                       // bits 2t, 2t + 1: sensed / occupancy run of row t undecided
+#pragma unroll 1
+            for (int t = 0; t < 5; ++t) {
+                const int k = -7 + (sub - 1) + 3 * t;               // wave-uniform
+                und |= lat_row(P, A, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e) << (2 * t);
+            }
+            while (__ballot(und != 0)) {                            // rare: a run end within rounding distance of its circle
+                if (und) {
+                    const int b = __ffs(und) - 1; und &= und - 1;
+                    const int k = -7 + (sub - 1) + 3 * (b >> 1);
+                    if (b & 1) lat_row_exact<false>(P, tab, A.vb, k, A.ub, 4, lat_cols, lat_rows, px, py, gxe, gye, nullptr, occ_e, cov_e);
+                    else lat_row_exact<true>(P, tab, A.vb, k, A.ub, 7, lat_cols, lat_rows, px, py, gxe, gye, mrow, nullptr, nullptr);
+                }
+            }
+            // nearest-cell screen over the compacted boundary cells: per 32-cell word the smallest s32 (as in the pass
+            // over all cells below); which cell it is is settled in P4
+            const int nbw = ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5;
+            const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+            const float *bxe = lat_cbx + es * ASM_LAT_NB, *bye = lat_cby + es * ASM_LAT_NB;
+            for (int w = sub - 1; w < nbw; w += 3) {
+                unsigned k1 = 0xFFFFFFFFu;
+                const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
+                const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float4 x4 = X[q], y4 = Y[q];
+                    const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                    const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                    const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                    const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                    k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
+                    k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+                }
+                lat_wkey[(size_t)l * (ASM_LAT_NB / 32) + w] = k1;
+                if (k1 < G1) G1w = (unsigned)w;
+                G2 = umed3(G1, G2, k1);
+                G1 = G1 < k1 ? G1 : k1;
+            }
+            if (sub == 3) {
+                double sq = __builtin_inf(); int iq = 0x7FFFFFFF;
+                if (A.inr) {
+                    const int du = A.fu < 0.f ? -1 : 1, dw = A.fv < 0.f ? -1 : 1;
+                    lat_site_exact(tab, A.ub, A.vb, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
+                    lat_site_exact(tab, A.ub + du, A.vb, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
+                    lat_site_exact(tab, A.ub, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
+                    lat_site_exact(tab, A.ub + du, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
+                }
+                unsigned *qs = reinterpret_cast<unsigned *>(L.rpart);                   // free until P6
+                qs[l] = (unsigned)__double2loint(sq); qs[64 + l] = (unsigned)__double2hiint(sq); qs[128 + l] = (unsigned)iq;
+            }
+        }
+        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, 0u);
+    } else {
         // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest
         // s32 is tracked (two cells per v_min3_u32); which cell it belongs to, and whether another cell is too
         // close to tell in single precision, is settled in P4 by screening the one word that holds it once more.
@@ -454,16 +573,20 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             // evaluated in double; ascending index + strict '<' gives the reference's first minimum (CPP:889).
             const unsigned lo = G1 >> 5;
             unsigned minw = 1u << G1w;
+            // lattice path: the words are those of the compacted boundary list
+            const int nwords = LAT ? ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5 : W;
+            const float *cxe = LAT ? lat_cbx + es * ASM_LAT_NB : gxe, *cye = LAT ? lat_cby + es * ASM_LAT_NB : gye;
+            [[maybe_unused]] const unsigned short *lat_bl = reinterpret_cast<const unsigned short *>(lat_tabs + es * LAT_TAB_BYTES + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
             if (!((G2 >> 5) - lo >= 2u)) {
-                const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
-                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
+                const unsigned *wkey = LAT ? lat_wkey + (size_t)l * (ASM_LAT_NB / 32) : reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
+                for (int w = 0; w < nwords; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
             }
             const unsigned lim = (lo << 5) + 64u;                   // candidate <=> bits(s32) < lim
             const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
             while (minw) {
                 const int w = __ffs(minw) - 1; minw &= minw - 1;
-                const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
-                const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
+                const float4 *X = reinterpret_cast<const float4 *>(cxe + w * 32);
+                const float4 *Y = reinterpret_cast<const float4 *>(cye + w * 32);
                 unsigned cand = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -480,10 +603,18 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 cand = __brev(cand);
                 while (cand) {
                     const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
-                    const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
+                    const double dx = (double)cxe[c] - px, dy = (double)cye[c] - py;
                     const double sd = dx * dx + dy * dy;
-                    if (sd < smin) { smin = sd; imin = c; }
+                    if (sd < smin) { smin = sd; imin = LAT ? (int)lat_bl[c] : c; }   // ascending cell index either way
                 }
+            }
+            if constexpr (LAT) {
+                // the four lattice sites around the agent (wave 3, P3): smaller distance wins, equal distances go to the
+                // lower cell index (the reference's first minimum, CPP:889)
+                const unsigned *qs = reinterpret_cast<const unsigned *>(L.rpart);
+                const double sq = __hiloint2double((int)qs[64 + l], (int)qs[l]);
+                const int iq = (int)qs[128 + l];
+                if (sq < smin || (sq == smin && iq < imin)) { smin = sq; imin = iq; }
             }
             if (ambw) {
                 // Rare: sensed bits within the margin of T_sen, decided in double

@@ -540,7 +540,7 @@ __global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t en
                         const double *shape_grids, const int *shape_off, const int *shape_ng,
                         const double *shape_lcell, int *shape_id_g, S *p_g, S *dp_g, S *grid_g, int *ng_g,
                         double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, int *sensed_g,
-                        int *occup_g)
+                        int *occup_g, double *xform_g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
@@ -573,7 +573,10 @@ __global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t en
         }
         const double coin = draw_uniform(seed, env, episode, d++, -1.0, 1.0);                              // ENV:197
         const uint32_t dpos = d, dctr = d + 2u * (uint32_t)n_a, dvel = dctr + 2u;
-        if (i == 0) { shape_id_g[e] = s; ng_g[e] = n_g; lcell_g[e] = l_cell; }
+        if (i == 0) {
+            shape_id_g[e] = s; ng_g[e] = n_g; lcell_g[e] = l_cell;
+            if (xform_g) { xform_g[(size_t)e * 4] = ca; xform_g[(size_t)e * 4 + 1] = sa; xform_g[(size_t)e * 4 + 2] = ox; xform_g[(size_t)e * 4 + 3] = oy; }
+        }
         if (active) {
             double x, y;
             if (coin > 0) {                                                                                // ENV:198-200

@@ -1,0 +1,180 @@
+// Lattice path of k_step_fast: the agent x cell work done on the shape's lattice instead of over all cells.
+// Part of the single translation unit asm_kernels.hip (included there, inside namespace asmenv); not a stand-alone header.
+//
+// Every target shape is a row-major subset of a regular lattice (asm_lattice_shape, include/marl_amd_env.h), placed
+// in the arena by a rotation and an offset (assembly.py:170-182).  In lattice coordinates (u, v) of an agent:
+//   * the cells within d_sen are, per lattice row, the sites |a - u| < sqrt(R^2 - (b - v)^2), R = d_sen / l_cell:
+//     one run of consecutive columns, hence (cells are numbered row by row) one run of consecutive cell indices,
+//     found with two popcounts on the row's occupancy bits;
+//   * the cells within r_avoid/2 (occupancy, coverage) likewise, on the few rows around the agent;
+//   * the nearest cell is a boundary cell of the shape or one of the four sites around (u, v): an interior cell
+//     (all four neighbours present) is nearest only to points of its own unit box, and any cell outside the four
+//     sites has a present neighbour that is closer by at least l_cell^2.
+// The reference decides on double-precision distances to the STORED float coordinates, which differ from the ideal
+// lattice positions by their rounding (half an ulp each).  Each run end is therefore checked: if the ideal squared
+// distance of one of the four sites around the two ends lies within `band` of R^2 (band covers that rounding, the
+// single-precision evaluation here and a safety factor), the lane evaluates the whole row exactly, cell by cell, on
+// the stored coordinates.  The nearest cell is always settled by exact evaluation of the candidates.
+
+// Row table entry in LDS: { occupancy bits of columns 16 j .. 16 j + 31, index of the row's first cell at a column >= 16 j }
+__device__ __forceinline__ uint2 lat_entry(const unsigned char *tab, int Bp, int j)
+{
+    return *reinterpret_cast<const uint2 *>(tab + (Bp * ASM_LAT_CHUNKS + j) * 8);
+}
+
+__device__ __forceinline__ unsigned lat_bfm(int width, int offset)         // ((1 << width) - 1) << offset, width, offset in 0..31
+{
+    return __builtin_amdgcn_ubfe(0xFFFFFFFFu, 0, (unsigned)width) << offset;
+}
+
+// The run of cells of table row Bp at columns [A0, A0 + cnt): first cell index and count.  0 <= A0 < 16 * CHUNKS, 0 <= cnt <= 15.
+__device__ __forceinline__ void lat_run(const unsigned char *tab, int Bp, int A0, int cnt, int &c0, int &n)
+{
+    const int j = A0 >> 4, sh = A0 & 15;
+    const uint2 ent = lat_entry(tab, Bp, j);
+    n = __popc((ent.x >> sh) & lat_bfm(cnt, 0));
+    c0 = (int)ent.y + __popc(ent.x & lat_bfm(sh, 0));
+}
+
+// OR the bit run [c0, c0 + n) (n <= 31) into a bitmap of 32-bit words in LDS.
+__device__ __forceinline__ void lat_or_run(unsigned *words, int c0, int n)
+{
+    const int w = c0 >> 5, o = c0 & 31;
+    const unsigned long long m = (unsigned long long)lat_bfm(n, 0) << o;
+    atomicOr(&words[w], (unsigned)m);
+    if ((unsigned)(m >> 32)) atomicOr(&words[w + 1], (unsigned)(m >> 32));
+}
+
+// Lattice view of one lane's agent.
+struct LatLane {
+    int ub, vb;          // nearest lattice site (column, row)
+    float fu, fv;        // offset of the agent from it, in [-0.5, 0.5]
+    bool inr;            // the agent is close enough to the lattice's bounding box to sense or occupy anything
+    float R2, band;      // (d_sen / l_cell)^2 and the width of the undecided band around it
+    float Ro2, bando;    // the same for r_avoid / 2
+};
+
+// Exact evaluation of one lattice row for an agent: every present site in columns ub - half .. ub + half is tested on
+// the stored coordinates in double.  SENSE: sensed bits (s < T_sen, CPP:907) into the agent's mask; otherwise the
+// occupancy (CPP:190) and coverage (WRAP:67) bits into the environment's bitmaps.
+template <bool SENSE>
+__device__ __forceinline__ void lat_row_exact(const DevParams &P, const unsigned char *tab, int vb, int k, int ub, int half,
+                                              int cols, int rows, double px, double py, const float *gx, const float *gy,
+                                              unsigned *mrow, unsigned *occ_e, unsigned *cov_e)
+{
+    int Bp = vb + k + 1;
+    Bp = Bp < 0 ? 0 : (Bp > rows + 1 ? rows + 1 : Bp);
+    const int Af = ub - half > 0 ? ub - half : 0, Al = ub + half < cols - 1 ? ub + half : cols - 1;
+    if (Af > Al) return;
+    const int j = Af >> 4, sh = Af & 15;
+    const uint2 ent = lat_entry(tab, Bp, j);
+    unsigned word = (ent.x >> sh) & lat_bfm(Al - Af + 1, 0);
+    int c = (int)ent.y + __popc(ent.x & lat_bfm(sh, 0));
+    for (; word; word &= word - 1, ++c) {
+        const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
+        const double sd = dx * dx + dy * dy;
+        if (SENSE) {
+            if (sd < P.T_sen) atomicOr(&mrow[c >> 5], 1u << (c & 31));
+        } else {
+            if (sd < P.T_half_le) atomicOr(&occ_e[c >> 5], 1u << (c & 31));
+            if (sd < P.T_half_lt) atomicOr(&cov_e[c >> 5], 1u << (c & 31));
+        }
+    }
+}
+
+// One lattice row k (relative to the agent's nearest site) of the sensing pass; rows |k| <= KO also carry the occupancy run.
+// Returns bit 0: the sensed run of this row is undecided, bit 1: the occupancy run is (the caller then evaluates the row
+// exactly with lat_row_exact; nothing has been written for an undecided run).
+__device__ __forceinline__ unsigned lat_row(const DevParams &P, const LatLane &A, const unsigned char *tab, int k, bool occ_row,
+                                            int cols, int rows, unsigned *mrow, unsigned *occ_e, unsigned *cov_e)
+{
+    unsigned undecided = 0;
+    const float dv = (float)k - A.fv, dv2 = dv * dv;
+    int Bp = A.vb + k + 1;                                          // table row; rows 0 and rows + 1 are empty
+    Bp = Bp < 0 ? 0 : (Bp > rows + 1 ? rows + 1 : Bp);
+    {
+        const float nh2 = dv2 - A.R2;                               // -(half-width of the run)^2
+        const float h = __builtin_amdgcn_sqrtf(__builtin_fmaxf(-nh2, 0.f));
+        const float alo_f = __builtin_ceilf(A.fu - h), ahi_f = __builtin_floorf(A.fu + h);
+        const f32x2 ta = {alo_f - 1.f - A.fu, alo_f - A.fu}, tb = {ahi_f - A.fu, ahi_f + 1.f - A.fu}, n2 = {nh2, nh2};
+        const f32x2 ea = __builtin_elementwise_fma(ta, ta, n2), eb = __builtin_elementwise_fma(tb, tb, n2);
+        const float amb = __builtin_fminf(__builtin_fminf(__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)),
+                                          __builtin_fminf(__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)));
+        int alo = (int)alo_f;
+        const int ahi = (int)ahi_f;
+        alo = alo > -A.ub ? alo : -A.ub;                            // first existing column
+        const int A0 = A.inr ? A.ub + alo : 0;
+        int cnt = ahi - alo + 1;
+        cnt = cnt < 0 ? 0 : (cnt > 15 ? 15 : cnt);
+        cnt = (nh2 < 0.f && A.inr && A0 < cols) ? cnt : 0;
+        int c0, n;
+        lat_run(tab, Bp, A0 < 16 * ASM_LAT_CHUNKS ? A0 : 16 * ASM_LAT_CHUNKS - 1, cnt, c0, n);
+        const bool unc = A.inr && !(amb > A.band);
+        undecided = unc ? 1u : 0u;
+        if (n > 0 && !unc) lat_or_run(mrow, c0, n);
+    }
+    if (occ_row) {
+        const float nh2 = dv2 - A.Ro2;
+        const float h = __builtin_amdgcn_sqrtf(__builtin_fmaxf(-nh2, 0.f));
+        const float alo_f = __builtin_ceilf(A.fu - h), ahi_f = __builtin_floorf(A.fu + h);
+        const f32x2 ta = {alo_f - 1.f - A.fu, alo_f - A.fu}, tb = {ahi_f - A.fu, ahi_f + 1.f - A.fu}, n2 = {nh2, nh2};
+        const f32x2 ea = __builtin_elementwise_fma(ta, ta, n2), eb = __builtin_elementwise_fma(tb, tb, n2);
+        const float amb = __builtin_fminf(__builtin_fminf(__builtin_fabsf(ea.x), __builtin_fabsf(ea.y)),
+                                          __builtin_fminf(__builtin_fabsf(eb.x), __builtin_fabsf(eb.y)));
+        int alo = (int)alo_f;
+        const int ahi = (int)ahi_f;
+        alo = alo > -A.ub ? alo : -A.ub;
+        const int A0 = A.inr ? A.ub + alo : 0;
+        int cnt = ahi - alo + 1;
+        cnt = cnt < 0 ? 0 : (cnt > 15 ? 15 : cnt);
+        cnt = (nh2 < 0.f && A.inr && A0 < cols) ? cnt : 0;
+        int c0, n;
+        lat_run(tab, Bp, A0 < 16 * ASM_LAT_CHUNKS ? A0 : 16 * ASM_LAT_CHUNKS - 1, cnt, c0, n);
+        const bool unc = A.inr && !(amb > A.bando);
+        undecided |= unc ? 2u : 0u;
+        if (n > 0 && !unc) { lat_or_run(occ_e, c0, n); lat_or_run(cov_e, c0, n); }
+    }
+    return undecided;
+}
+
+// Exact squared distance to the cell at lattice site (column a, row b), if that site holds a cell; keeps the smaller
+// (distance, index) pair in (smin, imin).
+__device__ __forceinline__ void lat_site_exact(const unsigned char *tab, int a, int b, int cols, int rows, double px, double py,
+                                               const float *gx, const float *gy, double &smin, int &imin)
+{
+    if (a < 0 || a >= cols || b < 0 || b >= rows) return;
+    const int j = a >> 4, sh = a & 15;
+    const uint2 ent = lat_entry(tab, b + 1, j);
+    if (!((ent.x >> sh) & 1u)) return;
+    const int c = (int)ent.y + __popc(ent.x & lat_bfm(sh, 0));
+    const double dx = (double)gx[c] - px, dy = (double)gy[c] - py;
+    const double sd = dx * dx + dy * dy;
+    if (sd < smin || (sd == smin && c < imin)) { smin = sd; imin = c; }
+}
+
+// Debugging aid: counts the cells whose stored coordinates differ from the lattice description by more than tol.
+__global__ void k_check_lattice(int E, int n_g_max, const float *grid_g, const int *ng_g, LatArgs lat, double tol, int *n_bad)
+{
+    const int e = blockIdx.x;
+    if (e >= E) return;
+    int sid = lat.shape_id[e];
+    const bool sid_ok = sid >= 0 && sid < lat.n_shapes;
+    sid = sid_ok ? sid : 0;
+    const asm_lattice_shape *sh = lat.shapes + sid;
+    const int n_g = ng_g[e];
+    const double c = lat.xform[e * 4 + 0], s = lat.xform[e * 4 + 1], ox = lat.xform[e * 4 + 2], oy = lat.xform[e * 4 + 3];
+    int bad = (!sid_ok || n_g != sh->n_g) ? 1 : 0;
+    if (!bad)
+        for (int r = 1; r <= sh->rows; ++r)
+            for (int a = threadIdx.x; a < sh->cols; a += blockDim.x) {
+                const int j = a >> 4, b = a & 15;
+                const unsigned bits = sh->row_tab[r][j][0];
+                if (!((bits >> b) & 1u)) continue;
+                const int cell = (int)sh->row_tab[r][j][1] + __popc(bits & ((1u << b) - 1u));
+                const double gx = sh->x0 + a * sh->l_cell, gy = sh->y0 + (r - 1) * sh->l_cell;
+                const double x = (c * gx + s * gy) + ox, y = (-s * gx + c * gy) + oy;
+                const double fx = grid_g[(size_t)e * 2 * n_g_max + cell], fy = grid_g[(size_t)e * 2 * n_g_max + n_g_max + cell];
+                if (!(fabs(fx - x) <= tol) || !(fabs(fy - y) <= tol)) ++bad;
+            }
+    if (bad) atomicAdd(n_bad, bad);
+}

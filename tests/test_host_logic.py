@@ -147,3 +147,40 @@ def test_bench_roofline_inputs():
     assert r["achieved"] == pytest.approx(r["launches_in_flight"] * r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9)
     assert line["value"] == pytest.approx(line["config"]["global_envs"] * line["config"]["agents"] / (line["ms_per_step"] * 1e-3))
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] >= 1
+
+
+def test_lattice_tables_of_the_reference_shapes():
+    """asm_lattice_build (host code of the library): every cell is found again through the row windows, the
+    boundary list holds exactly the cells with a missing 4-neighbour, and non-lattice input is refused."""
+    from marl_amd import _lib
+    from marl_amd.shapes import load_shapes
+    lib = _lib.load()
+    l_cells, grids = load_shapes()
+    for l_cell, g in zip(l_cells, grids):
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        sh = _lib.AsmLatticeShape()
+        assert lib.asm_lattice_build(g.ctypes.data, g.shape[0], l_cell, ctypes.byref(sh)) == 0, lib.asm_last_error()
+        col = np.rint((g[:, 0] - g[:, 0].min()) / l_cell).astype(int); row = np.rint((g[:, 1] - g[:, 1].min()) / l_cell).astype(int)
+        assert (sh.cols, sh.rows, sh.n_g) == (col.max() + 1, row.max() + 1, g.shape[0])
+        assert sh.x0 == g[:, 0].min() and sh.y0 == g[:, 1].min() and sh.l_cell == l_cell
+        tab = np.ctypeslib.as_array(sh.row_tab)                      # [48][3][2]
+        sites = {(int(a), int(b)): c for c, (a, b) in enumerate(zip(col, row))}
+        for (a, b), c in sites.items():
+            for j in range(3):
+                if 16 * j <= a < 16 * j + 32:
+                    bits, first = int(tab[b + 1, j, 0]), int(tab[b + 1, j, 1])
+                    assert (bits >> (a - 16 * j)) & 1
+                    assert first + bin(bits & ((1 << (a - 16 * j)) - 1)).count("1") == c
+        assert sum(bin(int(tab[r, 0, 0]) & 0xFFFF).count("1") + bin(int(tab[r, 1, 0]) & 0xFFFF).count("1") + bin(int(tab[r, 2, 0])).count("1")
+                   for r in range(48)) == g.shape[0]
+        assert not tab[0].any() or int(tab[0, :, 0].sum()) == 0      # the row below the lattice is empty
+        want = [c for (a, b), c in sorted(sites.items(), key=lambda kv: kv[1])
+                if not all(n in sites for n in ((a + 1, b), (a - 1, b), (a, b + 1), (a, b - 1)))]
+        got = list(np.ctypeslib.as_array(sh.boundary)[:sh.n_boundary])
+        assert got == want and 100 < len(got) <= 256
+    g = np.ascontiguousarray(grids[0], dtype=np.float64).copy()
+    g[5, 0] += 0.3 * l_cells[0]
+    assert lib.asm_lattice_build(g.ctypes.data, g.shape[0], l_cells[0], ctypes.byref(_lib.AsmLatticeShape())) != 0
+    g = np.ascontiguousarray(grids[0][::-1], dtype=np.float64)        # lattice, but not in row-major order
+    assert lib.asm_lattice_build(g.ctypes.data, g.shape[0], l_cells[0], ctypes.byref(_lib.AsmLatticeShape())) != 0
+    assert b"order" in lib.asm_last_error()
