@@ -74,7 +74,8 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     constexpr int N = 8;
     thread_local Slot cache[N];
     thread_local int next = 0;
-    if (prm)
+    static const bool no_cache = std::getenv("MARL_AMD_NO_PARAM_CACHE") != nullptr;   // measurement knob (tools/host_launch_cost.py)
+    if (prm && !no_cache)
         for (int k = 0; k < N; ++k)
             if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && !std::memcmp(&cache[k].prm, prm, sizeof *prm)) {
                 *out = cache[k].P;

@@ -131,22 +131,37 @@ def test_wrapper_metrics_match_reference_values():
 
 
 def test_bench_roofline_inputs():
-    """The bench's roofline figures: algorithmic bytes per agent-step (872 + 8 n_g / n_a), the committed counter
-    summary it quotes the measured traffic from (only for the workload the counters were taken on), and the
-    committed bench line's internal consistency (achieved = launches in flight x bytes per launch / launch time)."""
+    """The bench's roofline figures: algorithmic bytes and FLOPs per agent-step, the committed counter summaries it
+    quotes the measured traffic from (only for the workload the counters were taken on), and the committed bench
+    lines' internal consistency: frac == value per GPU x algorithmic bytes (FLOPs) / peak, bound chosen by intensity."""
     import json
     import bench
     assert bench.b_alg_per_agent_step(30, 500.0) == pytest.approx(872 + 8 * 500 / 30)
+    assert bench.f_alg_per_agent_step(1024, 500.0) == pytest.approx(15 * 500 + 20 * 1023 + 2400)
     t = bench.measured_traffic(4096, 30, 2)
-    assert t is not None and t["hbm_bytes_per_launch"] > 0.9 * 2048 * 30 * bench.b_alg_per_agent_step(30, 511.8)
+    assert t is not None and t["source"] == "profiles/r02_pmc.json"
+    assert t["hbm_bytes_per_launch"] > 0.9 * 2048 * 30 * bench.b_alg_per_agent_step(30, 511.8)
     assert bench.measured_traffic(4096, 31, 2) is None
-    with open(os.path.join(REPO, "profiles", "r01_bench_default.json")) as f:
-        line = json.load(f)
-    r = line["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    assert r["achieved"] == pytest.approx(r["launches_in_flight"] * r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9)
-    assert line["value"] == pytest.approx(line["config"]["global_envs"] * line["config"]["agents"] / (line["ms_per_step"] * 1e-3))
-    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["cores"] >= 1
+    assert bench.measured_traffic(256, 1024, 1)["source"] == "profiles/r02_c4_pmc.json"
+    lines = [json.load(open(os.path.join(REPO, "profiles", "r02_bench_default.json"))),
+             json.load(open(os.path.join(REPO, "profiles", "r02_bench_steps20_warmup5.json")))]
+    lines += [json.loads(l) for l in open(os.path.join(REPO, "profiles", "r02_bench_variants.jsonl"))]
+    for line in lines:
+        r, c = line["roofline"], line["config"]
+        per_gpu = line["value"] / line["n_gpus"]
+        if c["agents"] == 1024:
+            assert r["bound"] == "valu" and r["peak"] == 157.3 and r["unit"] == "TFLOP/s"
+            assert r["achieved"] == pytest.approx(per_gpu * r["alg_flops_per_agent_step"] / 1e12)
+        else:
+            assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+            assert r["achieved"] == pytest.approx(per_gpu * r["alg_bytes_per_agent_step"] / 1e9)
+        assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+        assert line["value"] == pytest.approx(c["global_envs"] * c["agents"] / (line["ms_per_step"] * 1e-3))
+        assert line["timing"]["windows"] >= 5 and line["timing"]["steps_per_window"] == line["steps"]
+        assert f'{c["agents"]}-agent' in line["metric"]
+    # a 20-step run measures the same step time as the 2000-step run (both on one box, round 2)
+    assert lines[1]["ms_per_step"] == pytest.approx(lines[0]["ms_per_step"], rel=0.03)
+    assert lines[0]["cpu_baseline"]["kind"] in ("reference", "port") and lines[0]["cpu_baseline"]["cores"] >= 1
 
 
 def test_lattice_tables_of_the_reference_shapes():
