@@ -89,6 +89,9 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
+#ifndef ASM_SPARSE_MAX
+#define ASM_SPARSE_MAX 24    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent
+#endif
 template <int T, bool PER, int IDX, bool LAT>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
                                       // lists written (0 none, 1 sensed_index if given, 2 occupied_index too); LAT: the agent x
                                       // cell work runs on the shapes' lattice description (kernels_lattice.h; T = 4 only)
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         // Lattice path (kernels_lattice.h).  Wave 0 has the k-NN pass above; waves 1..3 share the 15 lattice rows the
         // sensing disc can cross (5 each) and the words of the compacted boundary list (nearest-cell screen); wave 3
         // also evaluates the four lattice sites around the agent exactly.
-        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0;
+        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, lat_any = 0;   // lat_any: this wave may have set sensed bits of the lane
         if (sub != 0) {
             LatLane A;
             {
@@ -452,8 +455,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #pragma unroll 1
             for (int t = 0; t < 5; ++t) {
                 const int k = -7 + (sub - 1) + 3 * t;               // wave-uniform
-                und |= lat_row(P, A, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e) << (2 * t);
+                const unsigned r = lat_row(P, A, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e);
+                und |= (r & 3u) << (2 * t);
+                lat_any |= r;                                       // bit 2 (a run with cells) or bit 0 (a row settled cell by cell)
             }
+            lat_any &= 5u;
             while (__ballot(und != 0)) {                            // rare: a run end within rounding distance of its circle
                 if (und) {
                     const int b = __ffs(und) - 1; und &= und - 1;
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 qs[l] = (unsigned)__double2loint(sq); qs[64 + l] = (unsigned)__double2hiint(sq); qs[128 + l] = (unsigned)iq;
             }
         }
-        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, 0u);
+        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, lat_any);
     } else {
         // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest
         // s32 is tracked (two cells per v_min3_u32); which cell it belongs to, and whether another cell is too
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const unsigned t = G1 > q.x ? G1 : q.x, m = G2 < q.y ? G2 : q.y;
             G2 = m < t ? m : t;
             G1 = G1 < q.x ? G1 : q.x;
-            ambw |= q.w;
+            if constexpr (!LAT) ambw |= q.w;                        // lattice path: that field says whether the wave found sensed cells
         }
         int imin = 0;
         double smin = __builtin_inf();
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         } else {
             L.fin[l] = 0;
         }
+        if constexpr (LAT) L.fin[64 + l] = 0;                       // list lengths of the sparse compaction (P5); empty lists stay 0
         if (T > 1 && P.want_stats)                                  // wave 1 computes the formation statistics in P7
             L.part[l] = make_uint4(__double2loint(dmin), __double2hiint(dmin), __double2loint(nn_min), __double2hiint(nn_min));
     }
@@ -663,129 +670,190 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const unsigned *mym = L.mask + (size_t)l * MW;
     const unsigned inm = in_flag ? 0xFFFFFFFFu : 0u;                // CPP:155: occupied cells drop out only inside the shape
     const int k0 = sub * cap / T, k1 = (sub + 1) * cap / T;         // this wave's observation slots (P6)
-    // Unused lanes sit at -1e30 (P0), so their masks are empty.  The words whose first rank lies below k0 form a
-    // prefix of nb words; this wave starts at the first non-empty word after them, whose first rank is bst.
-    int n_after = 0, nb = 0, bst = 0;
-    unsigned nz = 0;                                                // words with a cell that stays in the list
-    for (int w = 0; w < W; ++w) {
-        const unsigned f = mym[w] & ~(occ_e[w] & inm);
-        const int pc = __popc(f);
-        const bool below = n_after < k0;
-        n_after += pc;
-        nb += below ? 1 : 0;
-        bst = below ? n_after : bst;
-        nz |= (unsigned)(pc < 1 ? pc : 1) << w;
-    }
-    const unsigned nzs = nb >= 32 ? 0u : nz & (0xFFFFFFFFu << nb);
-    const bool found = nzs != 0;
-    const int wst = found ? __ffs(nzs) - 1 : 0;
-    const int n_out = n_after < cap ? n_after : cap;
     unsigned short *mysel = L.sel + (size_t)l * P.capp;
-    if (IDX >= 1 && sub == 0 && sensed_g) L.fin[64 + l] = (unsigned)n_out;      // for the row-wise copy of the lists in P6
-    STAMP(16);
-    [[maybe_unused]] int diag_it = 0;
-    {
-        // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
-        // rank k.  One loop per lane over its own set bits; the wave iterates as often as its busiest lane.
-        if (__ballot(n_after > cap) == 0) {
-            // Common case, no lane of the workgroup sub-samples: slot == rank.  Wave `sub` lists the words
-            // whose first rank lies in [k0, k1) (found above, so it starts without skipping anything).  The
-            // lane's next QN non-empty words are fetched into registers in one batch, so the loop below runs
-            // without waiting on LDS; a lane that needs more words finishes in the second loop.
-            constexpr int QN = 5;
-            bool busy = found && bst < k1;
-            int rank = bst;
-            nz &= 0xFFFFFFFFu << wst;
-            unsigned fq[QN], wq = 0;
-#pragma unroll
-            for (int q = 0; q < QN; ++q) {
-                const bool has = nz != 0;
-                const int wi = has ? __ffs(nz) - 1 : 0;
-                nz &= nz - 1;                                       // stays 0 once empty
-                const unsigned f = mym[wi] & ~(occ_e[wi] & inm);
-                fq[q] = has ? f : 0u;
-                wq |= (unsigned)wi << (5 * q);
+    int n_after = 0, n_out = 0;
+    // Lattice path: the waves of P3 know which agents sense anything at all.  When those are few (most agents are
+    // far from their shape under random actions) the lists are compacted agent by agent instead of lane by lane:
+    // the wave's cost then follows the number of cells actually listed, not the longest list among its 64 lanes.
+    bool sparse = false;
+    [[maybe_unused]] unsigned long long nzm = 0;
+    if constexpr (LAT) {
+        nzm = __ballot((L.part[64 + l].w | L.part[128 + l].w | L.part[192 + l].w) != 0);
+        sparse = __popcll(nzm) <= ASM_SPARSE_MAX;
+    }
+    if (sparse) {
+        // The non-empty agents are dealt out to the waves.  For one agent the 64 lanes test 64 cells (two mask words)
+        // per pass; a listed cell's slot is its rank among the listed cells (ballot prefix count), or, when the list
+        // is sub-sampled (n > cap, CPP:243-261), the slot k with t_k = rank, t_k = round(k (n-1) / (cap-1)).
+        const unsigned lanebit = 1u << (l & 31);
+        int turn = 0;
+        for (unsigned long long m = nzm; m; m &= m - 1) {
+            const int a = __builtin_ctzll(m);                       // wave-uniform
+            if ((turn++ & (T - 1)) != sub) continue;
+            const unsigned inma = (L.fin[a] >> 31) ? 0xFFFFFFFFu : 0u;          // CPP:155
+            const unsigned *ma = L.mask + (size_t)a * MW, *oa = L.occ + (a >> 5) * 2 * W;
+            const unsigned f = l < W ? ma[l] & ~(oa[l] & inma) : 0u;
+            const unsigned nzw = (unsigned)__ballot(f != 0);        // words with a cell that stays in the list (W <= 32)
+            unsigned short *sa = L.sel + (size_t)a * P.capp;
+            int n = 0;
+            for (unsigned pw = nzw; pw; ) {
+                const int q = __builtin_ctz(pw) >> 1;               // word pair
+                pw &= ~(3u << (2 * q));
+                const unsigned w0 = __builtin_amdgcn_readlane(f, 2 * q), w1 = __builtin_amdgcn_readlane(f, 2 * q + 1);
+                const bool has = ((l < 32 ? w0 : w1) & lanebit) != 0;
+                const unsigned long long bal = __ballot(has);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, (unsigned)n));
+                if (has && rank < cap) sa[rank] = (unsigned short)(q * 64 + l);
+                n += __popcll(bal);
             }
-            unsigned bits = fq[0];
-            busy = busy && bits != 0;
-            unsigned short *wp = mysel + rank, *const wend = mysel + k1;
-            unsigned wbase = (wq & 31u) << 5;
-            while (busy) {                                          // bits != 0 here; two cells of the word per trip
-                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
-                *wp = (unsigned short)(wbase | b);
-                // the word's next cell, if it has one, goes to the next slot in the same trip (no branch: without
-                // one the first cell is stored once more in place)
-                const bool two = bits != 0;
-                const unsigned b2 = (unsigned)(__ffs(bits) - 1); bits &= bits - 1;      // bits == 0 stays 0
-                wp[two ? 1 : 0] = (unsigned short)(wbase | (two ? b2 : b));
-                wp += two ? 2 : 1;
-                ++diag_it;
-                if (bits == 0) {
-#pragma unroll
-                    for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
-                    fq[QN - 1] = 0; wq >>= 5; wbase = (wq & 31u) << 5;
-                    bits = fq[0];
-                    if (bits == 0 || wp >= wend) busy = false;
+            if (n > cap) {                                          // sub-sampled list: slot k holds rank t_k
+                // (2r-1)(cap-1) <= 2k(n-1) < (2r+1)(cap-1)  <=>  t_k = r; at most one k per rank since n > cap
+                const int den = 2 * (n - 1), capm = cap - 1;
+                const float rden = 1.0f / (float)den;
+                int r0 = 0;
+                for (unsigned pw = nzw; pw; ) {
+                    const int q = __builtin_ctz(pw) >> 1;
+                    pw &= ~(3u << (2 * q));
+                    const unsigned w0 = __builtin_amdgcn_readlane(f, 2 * q), w1 = __builtin_amdgcn_readlane(f, 2 * q + 1);
+                    const bool has = ((l < 32 ? w0 : w1) & lanebit) != 0;
+                    const unsigned long long bal = __ballot(has);
+                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, (unsigned)r0));
+                    const int N = (2 * r - 1) * capm + den - 1;     // k = ceil((2r-1)(cap-1) / den) = floor(N / den), r >= 1
+                    int k = (int)((float)N * rden);                 // exact integers below 2^24; the quotient is off by one at most
+                    const int rem = N - k * den;
+                    k += rem < 0 ? -1 : (rem >= den ? 1 : 0);
+                    k = r == 0 ? 0 : k;
+                    if (has && k < cap && 2 * k * (n - 1) < (2 * r + 1) * capm) sa[k] = (unsigned short)(q * 64 + l);
+                    r0 += __popcll(bal);
                 }
             }
-            rank = (int)(wp - mysel);
-            busy = found && rank < k1 && nz != 0;                   // rare: more than QN words in this wave's range
-            bits = 0;
-            int w = 0;
-            while (busy) {
-                if (bits == 0) {
-                    if (nz == 0 || rank >= k1) { busy = false; continue; }
-                    w = __ffs(nz) - 1; nz &= nz - 1;
-                    bits = mym[w] & ~(occ_e[w] & inm);
+            if (l == 0) L.fin[64 + a] = (unsigned)n;                // read back by the agent's own lanes after the barrier
+        }
+    } else {
+        // Unused lanes sit at -1e30 (P0), so their masks are empty.  The words whose first rank lies below k0 form a
+        // prefix of nb words; this wave starts at the first non-empty word after them, whose first rank is bst.
+        int nb = 0, bst = 0;
+        unsigned nz = 0;                                                // words with a cell that stays in the list
+        for (int w = 0; w < W; ++w) {
+            const unsigned f = mym[w] & ~(occ_e[w] & inm);
+            const int pc = __popc(f);
+            const bool below = n_after < k0;
+            n_after += pc;
+            nb += below ? 1 : 0;
+            bst = below ? n_after : bst;
+            nz |= (unsigned)(pc < 1 ? pc : 1) << w;
+        }
+        const unsigned nzs = nb >= 32 ? 0u : nz & (0xFFFFFFFFu << nb);
+        const bool found = nzs != 0;
+        const int wst = found ? __ffs(nzs) - 1 : 0;
+        n_out = n_after < cap ? n_after : cap;
+        if (IDX >= 1 && sub == 0 && sensed_g) L.fin[64 + l] = (unsigned)n_out;      // for the row-wise copy of the lists in P6
+        STAMP(16);
+        [[maybe_unused]] int diag_it = 0;
+        {
+            // Slot k holds the set bit of rank t_k = round(k * (n-1)/(cap-1)) when n > cap (CPP:243-261), else
+            // rank k.  One loop per lane over its own set bits; the wave iterates as often as its busiest lane.
+            if (__ballot(n_after > cap) == 0) {
+                // Common case, no lane of the workgroup sub-samples: slot == rank.  Wave `sub` lists the words
+                // whose first rank lies in [k0, k1) (found above, so it starts without skipping anything).  The
+                // lane's next QN non-empty words are fetched into registers in one batch, so the loop below runs
+                // without waiting on LDS; a lane that needs more words finishes in the second loop.
+                constexpr int QN = 5;
+                bool busy = found && bst < k1;
+                int rank = bst;
+                nz &= 0xFFFFFFFFu << wst;
+                unsigned fq[QN], wq = 0;
+    #pragma unroll
+                for (int q = 0; q < QN; ++q) {
+                    const bool has = nz != 0;
+                    const int wi = has ? __ffs(nz) - 1 : 0;
+                    nz &= nz - 1;                                       // stays 0 once empty
+                    const unsigned f = mym[wi] & ~(occ_e[wi] & inm);
+                    fq[q] = has ? f : 0u;
+                    wq |= (unsigned)wi << (5 * q);
                 }
-                const int b = __ffs(bits) - 1; bits &= bits - 1;
-                mysel[rank++] = (unsigned short)(w * 32 + b);
-            }
-#ifdef ASM_DIAG
-            for (int m = 32; m >= 1; m >>= 1) diag_it = max(diag_it, __shfl_xor(diag_it, m, 64));
-            DIAG_COUNT(17, diag_it);
-#endif
-        } else {
-            DIAG_COUNT(18, 1);
-            // cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double evaluation
-            // rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced incrementally
-            // as quotient/remainder (increment exactly 1 for n <= cap).  Wave `sub` fills the slots [k0, k1).
-            const unsigned two_c = 2u * (unsigned)(cap - 1);
-            const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
-            const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
-            const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
-            unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0, wbase = 0;
-            // t_{k0} >= k0, and the words before word nb - 1 end below rank k0: the walk starts at word nb - 1,
-            // whose first rank is bst minus its own count
-            const int w0 = nb > 0 ? nb - 1 : 0;
-            int rank = nb > 0 ? bst - __popc(mym[w0] & ~(occ_e[w0] & inm)) : 0;
-            nz &= 0xFFFFFFFFu << w0;
-            unsigned short *wp = mysel + k0, *const wend = mysel + (k1 < n_out ? k1 : n_out);
-            bool busy = active && k0 < n_out;
-            while (busy) {
-                if (bits == 0) {
-                    if (nz == 0) { busy = false; continue; }
-                    const int w = __builtin_ctz(nz); nz &= nz - 1;
-                    bits = mym[w] & ~(occ_e[w] & inm);
-                    wbase = (unsigned)w << 5;
-                    const int pc = __popc(bits);
-                    if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
-                    for (int d = (int)tq - rank; d > 0; --d) bits &= bits - 1;             // so do its first tq - rank cells
-                    rank = rank < (int)tq ? (int)tq : rank;
+                unsigned bits = fq[0];
+                busy = busy && bits != 0;
+                unsigned short *wp = mysel + rank, *const wend = mysel + k1;
+                unsigned wbase = (wq & 31u) << 5;
+                while (busy) {                                          // bits != 0 here; two cells of the word per trip
+                    const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
+                    *wp = (unsigned short)(wbase | b);
+                    // the word's next cell, if it has one, goes to the next slot in the same trip (no branch: without
+                    // one the first cell is stored once more in place)
+                    const bool two = bits != 0;
+                    const unsigned b2 = (unsigned)(__ffs(bits) - 1); bits &= bits - 1;      // bits == 0 stays 0
+                    wp[two ? 1 : 0] = (unsigned short)(wbase | (two ? b2 : b));
+                    wp += two ? 2 : 1;
+                    ++diag_it;
+                    if (bits == 0) {
+    #pragma unroll
+                        for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
+                        fq[QN - 1] = 0; wq >>= 5; wbase = (wq & 31u) << 5;
+                        bits = fq[0];
+                        if (bits == 0 || wp >= wend) busy = false;
+                    }
                 }
-                const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
-                if ((unsigned)rank == tq) {
-                    *wp++ = (unsigned short)(wbase | b);
-                    tq += inc_q; tr += inc_r;
-                    if (tr >= two_c) { tr -= two_c; ++tq; }
-                    if (wp >= wend) busy = false;
+                rank = (int)(wp - mysel);
+                busy = found && rank < k1 && nz != 0;                   // rare: more than QN words in this wave's range
+                bits = 0;
+                int w = 0;
+                while (busy) {
+                    if (bits == 0) {
+                        if (nz == 0 || rank >= k1) { busy = false; continue; }
+                        w = __ffs(nz) - 1; nz &= nz - 1;
+                        bits = mym[w] & ~(occ_e[w] & inm);
+                    }
+                    const int b = __ffs(bits) - 1; bits &= bits - 1;
+                    mysel[rank++] = (unsigned short)(w * 32 + b);
                 }
-                ++rank;
+    #ifdef ASM_DIAG
+                for (int m = 32; m >= 1; m >>= 1) diag_it = max(diag_it, __shfl_xor(diag_it, m, 64));
+                DIAG_COUNT(17, diag_it);
+    #endif
+            } else {
+                DIAG_COUNT(18, 1);
+                // cap-1 is odd here, so k(n-1)/(cap-1) is never a half-integer and the reference's double evaluation
+                // rounds like the exact rational: t_k = floor((2k(n-1) + (cap-1)) / (2(cap-1))), advanced incrementally
+                // as quotient/remainder (increment exactly 1 for n <= cap).  Wave `sub` fills the slots [k0, k1).
+                const unsigned two_c = 2u * (unsigned)(cap - 1);
+                const unsigned num = n_after > cap ? 2u * (unsigned)(n_after - 1) : two_c;
+                const unsigned inc_q = num / two_c, inc_r = num - inc_q * two_c;
+                const unsigned n0 = (unsigned)k0 * num + (unsigned)(cap - 1);       // numerator of t_{k0}
+                unsigned tq = n0 / two_c, tr = n0 - tq * two_c, bits = 0, wbase = 0;
+                // t_{k0} >= k0, and the words before word nb - 1 end below rank k0: the walk starts at word nb - 1,
+                // whose first rank is bst minus its own count
+                const int w0 = nb > 0 ? nb - 1 : 0;
+                int rank = nb > 0 ? bst - __popc(mym[w0] & ~(occ_e[w0] & inm)) : 0;
+                nz &= 0xFFFFFFFFu << w0;
+                unsigned short *wp = mysel + k0, *const wend = mysel + (k1 < n_out ? k1 : n_out);
+                bool busy = active && k0 < n_out;
+                while (busy) {
+                    if (bits == 0) {
+                        if (nz == 0) { busy = false; continue; }
+                        const int w = __builtin_ctz(nz); nz &= nz - 1;
+                        bits = mym[w] & ~(occ_e[w] & inm);
+                        wbase = (unsigned)w << 5;
+                        const int pc = __popc(bits);
+                        if ((unsigned)(rank + pc) <= tq) { rank += pc; bits = 0; continue; }   // the whole word ranks below the next slot
+                        for (int d = (int)tq - rank; d > 0; --d) bits &= bits - 1;             // so do its first tq - rank cells
+                        rank = rank < (int)tq ? (int)tq : rank;
+                    }
+                    const unsigned b = (unsigned)__builtin_ctz(bits); bits &= bits - 1;
+                    if ((unsigned)rank == tq) {
+                        *wp++ = (unsigned short)(wbase | b);
+                        tq += inc_q; tr += inc_r;
+                        if (tr >= two_c) { tr -= two_c; ++tq; }
+                        if (wp >= wend) busy = false;
+                    }
+                    ++rank;
+                }
             }
         }
     }
     STAMP(6);
     if (T > 1) __syncthreads();                                     // the lists are complete
+    if (sparse) { n_after = (int)L.fin[64 + l]; n_out = n_after < cap ? n_after : cap; }
     STAMP(15);
     EXIT_AT(5);
 

@@ -84,7 +84,7 @@ __device__ __forceinline__ void lat_row_exact(const DevParams &P, const unsigned
 
 // One lattice row k (relative to the agent's nearest site) of the sensing pass; rows |k| <= KO also carry the occupancy run.
 // Returns bit 0: the sensed run of this row is undecided, bit 1: the occupancy run is (the caller then evaluates the row
-// exactly with lat_row_exact; nothing has been written for an undecided run).
+// exactly with lat_row_exact; nothing has been written for an undecided run); bit 2: the sensed run holds cells.
 __device__ __forceinline__ unsigned lat_row(const DevParams &P, const LatLane &A, const unsigned char *tab, int k, bool occ_row,
                                             int cols, int rows, unsigned *mrow, unsigned *occ_e, unsigned *cov_e)
 {
@@ -110,7 +110,7 @@ __device__ __forceinline__ unsigned lat_row(const DevParams &P, const LatLane &A
         int c0, n;
         lat_run(tab, Bp, A0 < 16 * ASM_LAT_CHUNKS ? A0 : 16 * ASM_LAT_CHUNKS - 1, cnt, c0, n);
         const bool unc = A.inr && !(amb > A.band);
-        undecided = unc ? 1u : 0u;
+        undecided = (unc ? 1u : 0u) | (n > 0 ? 4u : 0u);
         if (n > 0 && !unc) lat_or_run(mrow, c0, n);
     }
     if (occ_row) {
