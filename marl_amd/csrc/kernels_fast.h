@@ -90,7 +90,8 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #define ASM_FAST_MINW 1
 #endif
 #ifndef ASM_SPARSE_MAX
-#define ASM_SPARSE_MAX 24    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent
+#define ASM_SPARSE_MAX 64    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent (64: always;
+                             // measured as fast as the lane-by-lane loop even when every agent senses cells)
 #endif
 template <int T, bool PER, int IDX, bool LAT>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
                                       // lists written (0 none, 1 sensed_index if given, 2 occupied_index too); LAT: the agent x
@@ -135,19 +136,26 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     [[maybe_unused]] int lat_cols = 0, lat_rows = 0, lat_nb0 = 0, lat_nb1 = 0;
     [[maybe_unused]] double lat_x0 = 0, lat_y0 = 0, lat_invl = 1, xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
     [[maybe_unused]] uint4 lat_tv = make_uint4(0, 0, 0, 0);
+    // The shape ids first: everything else of the lattice hangs on them.  The dependent loads are issued after the grid
+    // loads below and their data is not needed before P3 (the tables reach LDS after the first barrier, the compacted
+    // boundary cells are built between the two barriers of the dynamics phase), so this second round trip to memory
+    // runs under the dynamics instead of delaying the first barrier.
+    [[maybe_unused]] int sid0 = 0, sid1 = 0;
     if constexpr (LAT) {
-        int sid0 = e0 < P.E ? lat.shape_id[e0] : 0, sid1 = e0 + 1 < P.E ? lat.shape_id[e0 + 1] : 0;
+        sid0 = e0 < P.E ? lat.shape_id[e0] : 0; sid1 = e0 + 1 < P.E ? lat.shape_id[e0 + 1] : 0;
+        if (env_ok) { xf_c = lat.xform[(size_t)e * 4]; xf_s = lat.xform[(size_t)e * 4 + 1]; xf_ox = lat.xform[(size_t)e * 4 + 2]; xf_oy = lat.xform[(size_t)e * 4 + 3]; }
+    }
+    auto lat_loads = [&]() {
         sid0 = sid0 < 0 ? 0 : (sid0 >= lat.n_shapes ? lat.n_shapes - 1 : sid0);
         sid1 = sid1 < 0 ? 0 : (sid1 >= lat.n_shapes ? lat.n_shapes - 1 : sid1);
         lat_nb0 = e0 < P.E ? lat.shapes[sid0].n_boundary : 0; lat_nb1 = e0 + 1 < P.E ? lat.shapes[sid1].n_boundary : 0;
         const asm_lattice_shape *sh = lat.shapes + (es ? sid1 : sid0);
         lat_cols = sh->cols; lat_rows = sh->rows; lat_x0 = sh->x0; lat_y0 = sh->y0; lat_invl = 1.0 / sh->l_cell;
-        if (env_ok) { xf_c = lat.xform[(size_t)e * 4]; xf_s = lat.xform[(size_t)e * 4 + 1]; xf_ox = lat.xform[(size_t)e * 4 + 2]; xf_oy = lat.xform[(size_t)e * 4 + 3]; }
         if (tid < 2 * LAT_TAB_VEC) {
             const int h = tid >= LAT_TAB_VEC ? 1 : 0;
             lat_tv = reinterpret_cast<const uint4 *>(lat.shapes + (h ? sid1 : sid0))[tid - h * LAT_TAB_VEC];
         }
-    }
+    };
     {
         float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
         if (sub == 0 && active) {
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
                     if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
                 }
+                if constexpr (LAT) if (base == 0) lat_loads();      // T = 4: every wave passes here exactly once
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = base + (q * 64 + l) * 4;
@@ -187,33 +196,34 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
         if (sub == 0) { L.px[l] = sa; L.py[l] = sb; L.vx[l] = sc; L.vy[l] = sd; }
-        if constexpr (LAT) {
-            if (tid < 2 * LAT_TAB_VEC) reinterpret_cast<uint4 *>(lat_tabs)[tid] = lat_tv;
+        if constexpr (LAT)
             for (int w = tid; w < 64 * MW; w += 64 * T) L.mask[w] = 0;   // the sensed masks are built by OR-ing runs of cells
-        }
     }
     __syncthreads();
     STAMP(1);
     EXIT_AT(1);
+    if constexpr (LAT)
+        if (tid < 2 * LAT_TAB_VEC) reinterpret_cast<uint4 *>(lat_tabs)[tid] = lat_tv;   // published by the next barrier
     // lattice path: the boundary cells' coordinates, compacted (the candidates of the nearest-cell pass).  Waves 2 and 3
-    // gather them, one environment each, while waves 0 and 1 run the dynamics; the next barrier publishes them.
+    // gather them, one environment each, between the two barriers of the dynamics phase (the first publishes the tables).
     [[maybe_unused]] float *lat_cbx = reinterpret_cast<float *>(L.sel), *lat_cby = lat_cbx + 2 * ASM_LAT_NB;   // [2][NB] each, aliasing the slot lists
     [[maybe_unused]] unsigned *lat_wkey = reinterpret_cast<unsigned *>(lat_cby + 2 * ASM_LAT_NB);            // [64][NB / 32]
-    if constexpr (LAT) {
-        if (sub >= 2) {
-            const int h = sub - 2, nbh = h ? lat_nb1 : lat_nb0;
-            const unsigned short *bl = reinterpret_cast<const unsigned short *>(lat_tabs + h * LAT_TAB_BYTES + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
-            const float *gxh = L.g + (size_t)h * NGP;
+    auto lat_compact = [&]() {
+        if constexpr (LAT) {
+            if (sub >= 2) {
+                const int h = sub - 2, nbh = h ? lat_nb1 : lat_nb0;
+                const unsigned short *bl = reinterpret_cast<const unsigned short *>(lat_tabs + h * LAT_TAB_BYTES + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
+                const float *gxh = L.g + (size_t)h * NGP;
 #pragma unroll
-            for (int k = l; k < ASM_LAT_NB; k += 64) {
-                float x = 1e30f, y = 1e30f;
-                if (k < nbh) { const int c = bl[k]; x = gxh[c]; y = gxh[c + ASM_GY_OFF]; }
-                lat_cbx[h * ASM_LAT_NB + k] = x; lat_cby[h * ASM_LAT_NB + k] = y;
+                for (int k = l; k < ASM_LAT_NB; k += 64) {
+                    float x = 1e30f, y = 1e30f;
+                    if (k < nbh) { const int c = bl[k]; x = gxh[c]; y = gxh[c + ASM_GY_OFF]; }
+                    lat_cbx[h * ASM_LAT_NB + k] = x; lat_cby[h * ASM_LAT_NB + k] = y;
+                }
             }
         }
-        if (P.observe_only) __syncthreads();                        // otherwise the barriers of the dynamics phase follow
-    }
 
+    };
     int contacts = 0;
     if (!P.observe_only) {                                          // reset / observe: the state is taken as it is
     float npx = 1e30f, npy = 1e30f, nvx = 0.f, nvy = 0.f;
@@ -307,12 +317,17 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     }
     STAMP(2);
     __syncthreads();                                                // all reads of the old state done
+    lat_compact();
     if (sub == 0 && active) {
         L.px[l] = npx; L.py[l] = npy; L.vx[l] = nvx; L.vy[l] = nvy;
         const size_t o = (size_t)e * 2 * n_a;
         p_g[o + i] = npx; p_g[o + n_a + i] = npy; dp_g[o + i] = nvx; dp_g[o + n_a + i] = nvy;
     }
     __syncthreads();
+    } else if constexpr (LAT) {
+        __syncthreads();
+        lat_compact();
+        __syncthreads();
     }
     STAMP(3);
     EXIT_AT(2);
@@ -763,7 +778,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 int rank = bst;
                 nz &= 0xFFFFFFFFu << wst;
                 unsigned fq[QN], wq = 0;
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < QN; ++q) {
                     const bool has = nz != 0;
                     const int wi = has ? __ffs(nz) - 1 : 0;
@@ -787,7 +802,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     wp += two ? 2 : 1;
                     ++diag_it;
                     if (bits == 0) {
-    #pragma unroll
+#pragma unroll
                         for (int q = 0; q + 1 < QN; ++q) fq[q] = fq[q + 1];
                         fq[QN - 1] = 0; wq >>= 5; wbase = (wq & 31u) << 5;
                         bits = fq[0];
