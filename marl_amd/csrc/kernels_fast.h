@@ -445,8 +445,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(4);
     if constexpr (LAT) {
         // Lattice path (kernels_lattice.h).  Wave 0 has the k-NN pass above; waves 1..3 share the 15 lattice rows the
-        // sensing disc can cross (5 each) and the words of the compacted boundary list (nearest-cell screen); wave 3
-        // also evaluates the four lattice sites around the agent exactly.
+        // sensing disc can cross (5 each); wave 3 also evaluates the four lattice sites around the agent exactly; all
+        // four share the words of the compacted boundary list (nearest-cell screen).
         unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, lat_any = 0;   // lat_any: this wave may have set sensed bits of the lane
         if (sub != 0) {
             LatLane A;
@@ -483,30 +483,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     else lat_row_exact<true>(P, tab, A.vb, k, A.ub, 7, lat_cols, lat_rows, px, py, gxe, gye, mrow, nullptr, nullptr);
                 }
             }
-            // nearest-cell screen over the compacted boundary cells: per 32-cell word the smallest s32 (as in the pass
-            // over all cells below); which cell it is is settled in P4
-            const int nbw = ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5;
-            const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
-            const float *bxe = lat_cbx + es * ASM_LAT_NB, *bye = lat_cby + es * ASM_LAT_NB;
-            for (int w = sub - 1; w < nbw; w += 3) {
-                unsigned k1 = 0xFFFFFFFFu;
-                const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
-                const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float4 x4 = X[q], y4 = Y[q];
-                    const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
-                    const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
-                    const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
-                    const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
-                    k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
-                    k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
-                }
-                lat_wkey[(size_t)l * (ASM_LAT_NB / 32) + w] = k1;
-                if (k1 < G1) G1w = (unsigned)w;
-                G2 = umed3(G1, G2, k1);
-                G1 = G1 < k1 ? G1 : k1;
-            }
             if (sub == 3) {
                 double sq = __builtin_inf(); int iq = 0x7FFFFFFF;
                 if (A.inr) {
@@ -519,6 +495,32 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 unsigned *qs = reinterpret_cast<unsigned *>(L.rpart);                   // free until P6
                 qs[l] = (unsigned)__double2loint(sq); qs[64 + l] = (unsigned)__double2hiint(sq); qs[128 + l] = (unsigned)iq;
             }
+        }
+        {
+        // nearest-cell screen over the compacted boundary cells: per 32-cell word the smallest s32 (as in the pass
+        // over all cells below); which cell it is is settled in P4
+        const int nbw = ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5;
+        const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+        const float *bxe = lat_cbx + es * ASM_LAT_NB, *bye = lat_cby + es * ASM_LAT_NB;
+        for (int w = (sub + T - 1) & (T - 1); w < nbw; w += T) {    // wave 0, busy with the k-NN pass, takes the last share
+            unsigned k1 = 0xFFFFFFFFu;
+            const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
+            const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x4 = X[q], y4 = Y[q];
+                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
+                k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+            }
+            lat_wkey[(size_t)l * (ASM_LAT_NB / 32) + w] = k1;
+            if (k1 < G1) G1w = (unsigned)w;
+            G2 = umed3(G1, G2, k1);
+            G1 = G1 < k1 ? G1 : k1;
+        }
         }
         L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, lat_any);
     } else {
