@@ -107,7 +107,7 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
     P.MW = (P.W | 1) < 9 ? 9 : (P.W | 1);
     size_t env_bytes = state_bytes * (4 * (size_t)P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.SL * P.MW + 2 * (size_t)P.W) +
                        2 * (size_t)P.SL * P.MW;                          // + 16-bit word keys of the large-swarm cell pass
-    env_bytes = (env_bytes + 15) / 16 * 16;
+    env_bytes = (env_bytes + 15) / 16 * 16 + 16;                         // + the step's contact counter
     P.lds_env_bytes = (unsigned)env_bytes;
     P.lds_block_bytes = (unsigned)(env_bytes * P.EPB);
     if (P.lds_block_bytes > 160 * 1024)

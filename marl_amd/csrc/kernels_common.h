@@ -40,6 +40,7 @@ struct EnvLds {
     S *px, *py, *vx, *vy, *gx, *gy;
     unsigned *mask, *occ, *cov;
     unsigned short *wkey;          // [SL][MW] upper half of the smallest key of every word (large-swarm cell pass)
+    int *cnt;                      // contact pairs of the environment's step (k_step)
 };
 
 template <typename S>
@@ -53,6 +54,7 @@ __device__ __forceinline__ EnvLds<S> carve(unsigned char *base, const DevParams 
     unsigned *u = reinterpret_cast<unsigned *>(L.gy + P.NGP);
     L.mask = u; L.occ = u + (size_t)P.SL * P.MW; L.cov = L.occ + P.W;
     L.wkey = reinterpret_cast<unsigned short *>(L.cov + P.W);
+    L.cnt = reinterpret_cast<int *>(b + P.lds_env_bytes - 16);          // the last 16 bytes of the environment's block
     return L;
 }
 

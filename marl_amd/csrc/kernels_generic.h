@@ -284,7 +284,39 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
 
     STAMP(8);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
-    if (P.want_stats) {
+    if (P.want_stats && swarm) {
+        // Whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials; two
+        // barriers in all (16-wave barriers are what this kernel waits on most).  The variance of the nearest-neighbour
+        // distances (WRAP:96) is taken as E[m^2] - mean^2 from one pass (relative error ~1e-13 at these magnitudes).
+        __syncthreads();                                                 // masks no longer needed
+        const int wave = i >> 6, nw = P.SL >> 6;
+        double *part = reinterpret_cast<double *>(L.mask);               // [nw][8]
+        const double mloc = active ? sqrt(nn_min) : 0.0;
+        double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0, mloc,
+                       active ? mloc : __builtin_inf(), active ? mloc : -__builtin_inf(), mloc * mloc};
+        if (wave == 0 && (i & 63) < P.W) v[2] += 65536.0 * __popc(L.cov[i & 63]);   // covered cells ride along (W <= 32 words)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
+            v[3] += __shfl_xor(v[3], m, 64); v[6] += __shfl_xor(v[6], m, 64);
+            v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
+        }
+        if ((i & 63) == 0) for (int q = 0; q < 7; ++q) part[wave * 8 + q] = v[q];
+        __syncthreads();
+        if (i == 0 && e < P.E) {
+            double rs = 0, ds = 0, ic = 0, ms = 0, sq = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+            for (int w = 0; w < nw; ++w) {
+                rs += part[w * 8]; ds += part[w * 8 + 1]; ic += part[w * 8 + 2]; ms += part[w * 8 + 3]; sq += part[w * 8 + 6];
+                lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
+            }
+            const double covered = floor(ic / 65536.0), inn = ic - 65536.0 * covered;    // both are small integers
+            const double mean = ms / n_a, var = sq / n_a - mean * mean;
+            double *st = stats_g + (size_t)e * 8;
+            st[0] += rs; st[1] += rs; st[2] += P.n_g_e > 0 ? covered / P.n_g_e : 0.0;   // rewards are 0 or 1
+            st[3] += (var - lo) / (hi - lo);                                 // WRAP:98-99
+            st[4] += (double)(contact_pairs < 0 ? *L.cnt : contact_pairs); st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+        }
+    } else if (P.want_stats) {
         __syncthreads();                                                 // masks no longer needed
         double *scr = reinterpret_cast<double *>(L.mask);                // 4 doubles per agent (MW >= 8 words)
         if (active) {
@@ -292,44 +324,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             scr[(size_t)i * 4 + 2] = dmin;   scr[(size_t)i * 4 + 3] = in_flag ? 1.0 : 0.0;
         }
         __syncthreads();
-        if (swarm) {
-            // whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials
-            const int wave = i >> 6, nw = P.SL >> 6;
-            double *part = scr + (size_t)4 * P.SL;                           // [nw][8] behind the per-agent values
-            double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0,
-                           active ? sqrt(nn_min) : 0.0, active ? sqrt(nn_min) : __builtin_inf(),
-                           active ? sqrt(nn_min) : -__builtin_inf(), 0.0};
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
-                v[3] += __shfl_xor(v[3], m, 64);
-                v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
-            }
-            if ((i & 63) == 0) for (int q = 0; q < 6; ++q) part[wave * 8 + q] = v[q];
-            __syncthreads();
-            double ms = 0;
-            for (int w = 0; w < nw; ++w) ms += part[w * 8 + 3];
-            const double mean = ms / n_a, dv = active ? sqrt(nn_min) - mean : 0.0;
-            double sq = dv * dv;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
-            if ((i & 63) == 0) part[wave * 8 + 6] = sq;
-            __syncthreads();
-            if (i == 0 && e < P.E) {
-                double rs = 0, ds = 0, inn = 0, var = 0, lo = __builtin_inf(), hi = -__builtin_inf();
-                for (int w = 0; w < nw; ++w) {
-                    rs += part[w * 8]; ds += part[w * 8 + 1]; inn += part[w * 8 + 2]; var += part[w * 8 + 6];
-                    lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
-                }
-                var /= n_a;
-                int covered = 0;
-                for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
-                double *st = stats_g + (size_t)e * 8;
-                st[0] += rs; st[1] += rs; st[2] += P.n_g_e > 0 ? (double)covered / P.n_g_e : 0.0;   // rewards are 0 or 1
-                st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
-                st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
-            }
-        } else if (i == 0 && e < P.E) {
+        if (i == 0 && e < P.E) {
             double rs = 0, rq = 0, ds = 0, inn = 0, ms = 0, lo = __builtin_inf(), hi = -__builtin_inf();
             for (int a = 0; a < n_a; ++a) {
                 double r = scr[(size_t)a * 4], m = scr[(size_t)a * 4 + 1];
@@ -344,7 +339,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             double *st = stats_g + (size_t)e * 8;
             st[0] += rs; st[1] += rq; st[2] += P.n_g_e > 0 ? (double)covered / P.n_g_e : 0.0;
             st[3] += (var - lo) / (hi - lo);                             // WRAP:98-99
-            st[4] += (double)contact_pairs; st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+            st[4] += (double)(contact_pairs < 0 ? *L.cnt : contact_pairs); st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
         }
     }
     STAMP(9);
@@ -406,6 +401,7 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     const int n_g = env_ok ? clamp_ng(ng_g[e], P.n_g_max) : 0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
+    if (i == 0) *L.cnt = 0;
     __syncthreads();
     STAMP(1);
 
@@ -508,17 +504,9 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
         }
     }
     STAMP(2);
-    // contact pairs of the environment (upper triangle, WRAP:141-145)
-    int contact_pairs = 0;
-    if (P.want_stats) {
-        __syncthreads();
-        int *cnt = reinterpret_cast<int *>(L.occ);
-        if (i == 0) cnt[0] = 0;
-        __syncthreads();
-        if (active && contacts) atomicAdd(&cnt[0], contacts);
-        __syncthreads();
-        contact_pairs = cnt[0];
-    }
+    // contact pairs of the environment (upper triangle, WRAP:141-145): summed into the environment's counter (zeroed
+    // before the first barrier); it is read in the statistics phase, several barriers on
+    if (P.want_stats && active && contacts) atomicAdd(L.cnt, contacts);
     __syncthreads();                                                             // all reads of the old state done
     if (active) {
         const S a = (S)npx, b = (S)npy, c = (S)nvx, d = (S)nvy;
@@ -530,7 +518,7 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     STAMP(3);
     DevParams Q = P; Q.n_g_e = n_g;
     observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
-               stats_g, contact_pairs);
+               stats_g, -1);
 }
 
 // ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset

@@ -150,3 +150,31 @@ def test_rule_expert_actions_match_oracle(torch_cuda, n_a, E):
     plain.reset()
     with pytest.raises(RuntimeError, match="keep_indices"):
         plain.rule_actions()
+
+
+@pytest.mark.parametrize("n_a,E", [(256, 5), (1024, 2), (100, 4)])
+def test_large_swarm_step_statistics(torch_cuda, n_a, E):
+    """The large-swarm kernel's in-step statistics (workgroup reductions, one-pass variance) against the metrics
+    kernel on the same states, the contact pairs against the metrics of the state the step started from, and the
+    reward / inside counts against the step's own outputs."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    env = BatchedAssemblyEnv(E, n_a, seed=n_a)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    cell = (torch.rand(E, n_a, device="cuda", generator=g) * env.n_g[:, None]).long()
+    env.p.copy_(torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a)) + 0.03 * torch.randn(E, 2, n_a, device="cuda", generator=g))
+    env.observe()
+    for t in range(3):
+        before = env.stats.clone()
+        pre = env.formation_metrics().cpu().numpy()
+        _, rew, *_ = env.step(env.random_actions(step=t))
+        d = (env.stats - before).cpu().numpy(); m = env.formation_metrics().cpu().numpy()
+        np.testing.assert_allclose(d[:, 2], m[:, 0], rtol=1e-12)
+        np.testing.assert_allclose(d[:, 3], m[:, 1], rtol=1e-5)
+        np.testing.assert_allclose(d[:, 5], m[:, 4], rtol=1e-5)
+        np.testing.assert_array_equal(d[:, 4], pre[:, 3])
+        assert pre[:, 3].sum() > 0                                   # packed swarms do touch
+        np.testing.assert_array_equal(d[:, 0], rew.sum(dim=(1, 2)).cpu().numpy())
+        np.testing.assert_array_equal(d[:, 7], env.in_flags.sum(dim=1).cpu().numpy())
+        assert (d[:, 6] == 1).all()
