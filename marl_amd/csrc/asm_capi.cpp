@@ -186,6 +186,20 @@ bool lattice_usable(const asm_lattice *lat, const asm_params *prm, DevParams *P,
     return true;
 }
 
+// The same description for the large-swarm schedule of k_step (one environment per workgroup, a lane per agent):
+// walls, fp32 state, and room in LDS for the tables and the compacted boundary cells.
+bool lattice_usable_swarm(const asm_lattice *lat, const asm_params *prm, DevParams *P, asmenv::LatArgs *out)
+{
+    DevParams Q = *P;
+    Q.fast_T = 4; Q.NGP = 0;                                            // borrow the checks that do not depend on the schedule
+    if (P->SL < 64 || P->EPB != 1 || P->periodic || !lattice_usable(lat, prm, &Q, out)) return false;
+    const unsigned extra = 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS + 2 * ASM_LAT_NB + 8 * ASM_LAT_NB;
+    if (P->lds_block_bytes + extra > 160 * 1024) return false;
+    P->lds_env_bytes += extra; P->lds_block_bytes += extra;
+    P->lat = 2; P->lat_KO = Q.lat_KO; P->lat_cb = Q.lat_cb;
+    return true;
+}
+
 int hip_fail(int rc, const char *what)
 {
     return fail(rc, "%s: HIP error %d (%s)", what, rc, hipGetErrorString((hipError_t)rc));
@@ -365,10 +379,11 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
     if (!a_prior) P.prior = 0;
     asmenv::LatArgs LA{};
     if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
+    else lattice_usable_swarm(lattice, prm, &P, &LA);
     int rc = P.fast_T
         ? asmenv::launch_step_fast(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
                                    a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream)
-        : asmenv::launch_step<float>(P, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+        : asmenv::launch_step<float>(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
                                      reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_batch_step_f32") : 0;
 }

@@ -32,7 +32,7 @@ struct DevParams {
     unsigned lds_env_bytes, lds_block_bytes;
     int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
     unsigned fast_lds_bytes;
-    int lat, lat_KO;                // k_step_fast lattice path: on/off; lattice rows |k| <= lat_KO can hold an occupied cell
+    int lat, lat_KO;                // lattice path: 0 off, 1 k_step_fast, 2 k_step (large swarms); lattice rows |k| <= lat_KO can hold an occupied cell
     float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)
     double T_sen;                   // norm < d_sen            CPP:663, 907
     double T_half_le;               // !(norm > r_avoid/2)     CPP:190
@@ -58,7 +58,7 @@ int launch_observe(const DevParams &P, const S *p, const S *dp, const S *heading
                    const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, int *sensed,
                    int *occupied, hipStream_t st);
 template <typename S>
-int launch_step(const DevParams &P, S *p, S *dp, const float *act, const S *grid, const int *n_g,
+int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float *act, const S *grid, const int *n_g,
                 const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
                 int *occupied, double *stats, hipStream_t st);
 template <typename S>

@@ -57,8 +57,8 @@ __device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double
 }
 
 #include "kernels_common.h"
-#include "kernels_generic.h"
 #include "kernels_lattice.h"
+#include "kernels_generic.h"
 #include "kernels_fast.h"
 #include "kernels_aux.h"
 #include "kernels_compat.h"
@@ -127,12 +127,12 @@ int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp
 }
 
 template <typename S>
-int launch_step(const DevParams &P, S *p, S *dp, const float *act, const S *grid, const int *n_g,
+int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float *act, const S *grid, const int *n_g,
                 const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
                 int *occupied, double *stats, hipStream_t st)
 {
     if (int rc = set_lds(k_step<S>, P.lds_block_bytes)) return rc;
-    hipLaunchKernelGGL(k_step<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, p, dp, act, grid, n_g, l_cell,
+    hipLaunchKernelGGL(k_step<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, lat, p, dp, act, grid, n_g, l_cell,
                        nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
     LAUNCH_CHECK();
     return 0;
@@ -158,7 +158,7 @@ template int launch_observe<float>(const DevParams &, const float *, const float
 template int launch_observe<double>(const DevParams &, const double *, const double *, const double *, const double *,
                                     const int *, const double *, int *, int *, int *, double *, double *, int *, int *,
                                     hipStream_t);
-template int launch_step<float>(const DevParams &, float *, float *, const float *, const float *, const int *,
+template int launch_step<float>(const DevParams &, const LatArgs &, float *, float *, const float *, const float *, const int *,
                                 const double *, int *, int *, int *, float *, float *, float *, int *, int *, double *,
                                 hipStream_t);
 template int launch_reset<float>(const DevParams &, uint64_t, uint32_t, int64_t, int, const double *, const int *,

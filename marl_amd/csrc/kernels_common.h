@@ -31,6 +31,11 @@ __device__ __forceinline__ double draw_uniform(uint64_t seed, uint64_t env, uint
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// LDS of the lattice path per environment in the generic kernels: tables as in asm_lattice_shape (row windows, boundary
+// list), then x and y of the compacted boundary cells
+#define ASM_LAT_TAB_BYTES (8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS + 2 * ASM_LAT_NB)
+#define ASM_LAT_LDS_BYTES (ASM_LAT_TAB_BYTES + 8 * ASM_LAT_NB)
+
 // n_g[e] is caller data in device memory: the kernels read cells [0, min(max(n_g, 0), row length)) whatever it holds
 __device__ __forceinline__ int clamp_ng(int n_g, int n_g_max) { return n_g < 0 ? 0 : (n_g > n_g_max ? n_g_max : n_g); }
 
@@ -41,6 +46,7 @@ struct EnvLds {
     unsigned *mask, *occ, *cov;
     unsigned short *wkey;          // [SL][MW] upper half of the smallest key of every word (large-swarm cell pass)
     int *cnt;                      // contact pairs of the environment's step (k_step)
+    unsigned char *lat;            // lattice path of k_step: row windows + boundary list, then the compacted boundary coordinates
 };
 
 template <typename S>
@@ -55,6 +61,7 @@ __device__ __forceinline__ EnvLds<S> carve(unsigned char *base, const DevParams 
     L.mask = u; L.occ = u + (size_t)P.SL * P.MW; L.cov = L.occ + P.W;
     L.wkey = reinterpret_cast<unsigned short *>(L.cov + P.W);
     L.cnt = reinterpret_cast<int *>(b + P.lds_env_bytes - 16);          // the last 16 bytes of the environment's block
+    L.lat = b + P.lds_env_bytes - 16 - ASM_LAT_LDS_BYTES;               // only there when P.lat == 2
     return L;
 }
 

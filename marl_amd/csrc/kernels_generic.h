@@ -14,7 +14,7 @@
 template <typename S>
 __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, double l_cell,
                         const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
-                        int *sensed_g, int *occup_g, double *stats_g, int contact_pairs)
+                        int *sensed_g, int *occup_g, double *stats_g, int contact_pairs, const LatView *LV = nullptr)
 {
     constexpr bool F32 = sizeof(S) == 4;
     const int n_a = P.n_a;
@@ -150,8 +150,11 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         bool done = false;
         if constexpr (F32) {
             if (swarm) {
-                imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW,
-                                       L.wkey + (size_t)i * P.MW, L.occ, L.cov);
+                if (LV)                                                  // the shapes' lattice description is at hand
+                    imin = lat_cell_pass_lane(P, *LV, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW, L.occ, L.cov);
+                else
+                    imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW,
+                                           L.wkey + (size_t)i * P.MW, L.occ, L.cov);
                 done = true;
             } else
                 done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
@@ -388,7 +391,7 @@ __global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *hea
 
 // ENV:482-661: forces + prior on the old state, integration, observation + reward.
 template <typename S>
-__global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S *grid_g, const int *ng_g,
+__global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *act_g, const S *grid_g, const int *ng_g,
                        const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
                        S *prior_g, int *sensed_g, int *occup_g, double *stats_g)
 {
@@ -402,8 +405,34 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     if (i == 0) *L.cnt = 0;
+    // lattice path (large swarms, one environment per workgroup): the shape's tables into LDS now, the compacted
+    // boundary coordinates after the barrier (they come out of the grid in LDS); the barriers of the dynamics phase
+    // publish both before the observation uses them
+    LatView LV;
+    [[maybe_unused]] int lat_sid = 0;
+    if constexpr (sizeof(S) == 4) {
+        if (P.lat == 2) {
+            lat_sid = env_ok ? lat.shape_id[e] : 0;
+            lat_sid = lat_sid < 0 ? 0 : (lat_sid >= lat.n_shapes ? lat.n_shapes - 1 : lat_sid);
+            const asm_lattice_shape *sh = lat.shapes + lat_sid;
+            for (int k = i; k < ASM_LAT_TAB_BYTES / 16; k += P.SL) reinterpret_cast<uint4 *>(L.lat)[k] = reinterpret_cast<const uint4 *>(sh)[k];
+            LV.tab = L.lat; LV.cbx = reinterpret_cast<const float *>(L.lat + ASM_LAT_TAB_BYTES); LV.cby = LV.cbx + ASM_LAT_NB;
+            LV.cols = sh->cols; LV.rows = sh->rows; LV.nb = env_ok ? sh->n_boundary : 0;
+            LV.x0 = sh->x0; LV.y0 = sh->y0; LV.invl = 1.0 / sh->l_cell;
+            LV.c = 1; LV.s = 0; LV.ox = 0; LV.oy = 0;
+            if (env_ok) { LV.c = lat.xform[(size_t)e * 4]; LV.s = lat.xform[(size_t)e * 4 + 1]; LV.ox = lat.xform[(size_t)e * 4 + 2]; LV.oy = lat.xform[(size_t)e * 4 + 3]; }
+        }
+    }
     __syncthreads();
     STAMP(1);
+    if constexpr (sizeof(S) == 4) {
+        if (P.lat == 2)
+            for (int k = i; k < ASM_LAT_NB; k += P.SL) {
+                float x = 1e30f, y = 1e30f;
+                if (k < LV.nb) { const int c = lat.shapes[lat_sid].boundary[k]; x = L.gx[c]; y = L.gy[c]; }
+                const_cast<float *>(LV.cbx)[k] = x; const_cast<float *>(LV.cby)[k] = y;
+            }
+    }
 
     double npx = 0, npy = 0, nvx = 0, nvy = 0;
     int contacts = 0;
@@ -518,7 +547,7 @@ __global__ void k_step(DevParams P, S *p_g, S *dp_g, const float *act_g, const S
     STAMP(3);
     DevParams Q = P; Q.n_g_e = n_g;
     observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
-               stats_g, -1);
+               stats_g, -1, (sizeof(S) == 4 && P.lat == 2) ? &LV : nullptr);
 }
 
 // ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset

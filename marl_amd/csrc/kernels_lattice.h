@@ -152,6 +152,117 @@ __device__ __forceinline__ void lat_site_exact(const unsigned char *tab, int a, 
     if (sd < smin || (sd == smin && c < imin)) { smin = sd; imin = c; }
 }
 
+// The lattice data of one environment as the generic kernels hold it (one lane per agent, every lane doing its own
+// whole cell pass): tables and compacted boundary coordinates in LDS, geometry and placement in registers.
+struct LatView {
+    const unsigned char *tab;        // row windows (8 * ROWS * CHUNKS bytes), then the boundary list
+    const float *cbx, *cby;          // [ASM_LAT_NB] coordinates of the boundary cells, 1e30 beyond n_boundary
+    int cols, rows, nb;
+    double x0, y0, invl, c, s, ox, oy;
+};
+
+// Whole cell pass of one agent on the lattice: sensed mask (the lane's own mask row, cleared here), occupancy and
+// coverage bits, nearest cell (first minimum).  Same results as cell_pass_words.
+__device__ __forceinline__ int lat_cell_pass_lane(const DevParams &P, const LatView &V, bool active, float pxf, float pyf,
+                                                  const float *gx, const float *gy, unsigned *mrow, unsigned *occ, unsigned *cov)
+{
+    const double px = pxf, py = pyf;
+    for (int w = 0; w < P.W; ++w) mrow[w] = 0;
+    LatLane A;
+    {
+        const double rxp = px - V.ox, ryp = py - V.oy;
+        const double cxl = V.c * rxp - V.s * ryp, cyl = V.s * rxp + V.c * ryp;
+        double ud = (cxl - V.x0) * V.invl, vd = (cyl - V.y0) * V.invl;
+        ud = fmin(fmax(ud, -1000.0), 1000.0); vd = fmin(fmax(vd, -1000.0), 1000.0);
+        const double ur = rint(ud), vr = rint(vd);
+        A.ub = (int)ur; A.vb = (int)vr; A.fu = (float)(ud - ur); A.fv = (float)(vd - vr);
+        A.inr = active && A.ub >= -7 && A.ub <= V.cols + 6 && A.vb >= -7 && A.vb <= V.rows + 6;
+        const double Rd = P.d_sen * V.invl, Rod = P.r_avoid * 0.5 * V.invl;
+        const float invl_f = (float)V.invl;
+        A.R2 = (float)(Rd * Rd); A.Ro2 = (float)(Rod * Rod);
+        A.band = P.lat_cb * (float)Rd * invl_f + 4e-6f * A.R2;
+        A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
+    }
+    unsigned und = 0;                                               // 2 bits per row, 15 rows
+#pragma unroll 1
+    for (int t = 0; t < 15; ++t) {
+        const int k = t - 7;
+        und |= (lat_row(P, A, V.tab, k, k >= -P.lat_KO && k <= P.lat_KO, V.cols, V.rows, mrow, occ, cov) & 3u) << (2 * t);
+    }
+    while (und) {                                                   // rare: a run end within rounding distance of its circle
+        const int b = __ffs(und) - 1; und &= und - 1;
+        const int k = (b >> 1) - 7;
+        if (b & 1) lat_row_exact<false>(P, V.tab, A.vb, k, A.ub, 4, V.cols, V.rows, px, py, gx, gy, nullptr, occ, cov);
+        else lat_row_exact<true>(P, V.tab, A.vb, k, A.ub, 7, V.cols, V.rows, px, py, gx, gy, mrow, nullptr, nullptr);
+    }
+    // nearest cell: screen of the compacted boundary cells word by word, candidates settled in double, then the four
+    // lattice sites around the agent
+    const int nbw = (V.nb + 31) >> 5;
+    const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+    unsigned kw[ASM_LAT_NB / 32], G1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < ASM_LAT_NB / 32; ++w) {
+        unsigned k1 = 0xFFFFFFFFu;
+        if (w < nbw) {
+            const float4 *X = reinterpret_cast<const float4 *>(V.cbx + w * 32);
+            const float4 *Y = reinterpret_cast<const float4 *>(V.cby + w * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x4 = X[q], y4 = Y[q];
+                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
+                k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+            }
+        }
+        kw[w] = k1;
+        G1 = G1 < k1 ? G1 : k1;
+    }
+    double best = __builtin_inf(); int imin = 0x7FFFFFFF;
+    if (active) {
+        const unsigned lo = G1 >> 5, lim = (lo << 5) + 64u;
+        const unsigned short *bl = reinterpret_cast<const unsigned short *>(V.tab + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
+        unsigned minw = 0;
+#pragma unroll
+        for (int w = 0; w < ASM_LAT_NB / 32; ++w) minw |= ((kw[w] >> 5) - lo < 2u ? 1u : 0u) << w;
+        while (minw) {
+            const int w = __ffs(minw) - 1; minw &= minw - 1;
+            const float4 *X = reinterpret_cast<const float4 *>(V.cbx + w * 32);
+            const float4 *Y = reinterpret_cast<const float4 *>(V.cby + w * 32);
+            unsigned cand = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 x4 = X[q], y4 = Y[q];
+                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.x) - lim, 31);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.y) - lim, 31);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.x) - lim, 31);
+                cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.y) - lim, 31);
+            }
+            cand = __brev(cand);
+            while (cand) {
+                const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
+                const double dx = (double)V.cbx[c] - px, dy = (double)V.cby[c] - py;
+                const double sd = dx * dx + dy * dy;
+                if (sd < best) { best = sd; imin = (int)bl[c]; }    // the list ascends in cell index
+            }
+        }
+        if (A.inr) {
+            const int du = A.fu < 0.f ? -1 : 1, dw = A.fv < 0.f ? -1 : 1;
+            lat_site_exact(V.tab, A.ub, A.vb, V.cols, V.rows, px, py, gx, gy, best, imin);
+            lat_site_exact(V.tab, A.ub + du, A.vb, V.cols, V.rows, px, py, gx, gy, best, imin);
+            lat_site_exact(V.tab, A.ub, A.vb + dw, V.cols, V.rows, px, py, gx, gy, best, imin);
+            lat_site_exact(V.tab, A.ub + du, A.vb + dw, V.cols, V.rows, px, py, gx, gy, best, imin);
+        }
+    }
+    return imin == 0x7FFFFFFF ? 0 : imin;
+}
+
 // Debugging aid: counts the cells whose stored coordinates differ from the lattice description by more than tol.
 __global__ void k_check_lattice(int E, int n_g_max, const float *grid_g, const int *ng_g, LatArgs lat, double tol, int *n_bad)
 {

@@ -126,3 +126,30 @@ def test_lattice_path_full_size_and_off(torch_cuda):
     act = a.random_actions(step=99)
     a.step(act); b.step(act)
     _same(torch, a, b, "after invalidate")
+
+
+@pytest.mark.parametrize("n_a,E", [(100, 9), (256, 5), (1024, 2)])
+def test_lattice_path_large_swarms(torch_cuda, n_a, E):
+    """The large-swarm schedule (a lane per agent, one environment per workgroup) with and without the lattice
+    description: bit-equal, random and packed, and equal to the oracle."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, teacher_forced_step
+    a, b = _pair(E, n_a=n_a, seed=n_a)
+    a.reset(); b.reset()
+    for t in range(3):
+        act = a.random_actions(step=t)
+        a.step(act); b.step(act)
+        _same(torch, a, b, f"swarm random {t}")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cell = (torch.rand(E, n_a, device="cuda", generator=g) * a.n_g[:, None]).long()
+    pos = torch.gather(a.grid_center, 2, cell[:, None, :].expand(E, 2, n_a)) + 0.03 * torch.randn(E, 2, n_a, device="cuda", generator=g)
+    for env in (a, b):
+        env.p.copy_(pos); env.observe()
+    cfg = cfg_from_env(a)
+    rng = np.random.default_rng(1)
+    for t in range(2):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        teacher_forced_step(a, cfg, act, f"swarm packed {t}")
+        b.step(torch.from_numpy(act).cuda())
+        _same(torch, a, b, f"swarm packed {t}")
+    assert torch.allclose(a.stats, b.stats, rtol=1e-12, atol=0)
