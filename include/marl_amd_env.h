@@ -300,9 +300,10 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
 /* index[k] = lo + floor(u_k * (hi - lo)) with u_k from the counter-based generator (key = seed,
  * counter = (k, counter), stream 2): uniform transition ids WITH replacement (buffer_agent.py:149-154
  * draws without replacement; with >= 1e7 stored rows and 2048 draws the difference is ~2e-4 expected
- * duplicates per batch). */
-int asm_replay_draw_indices(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N,
-                            int64_t *index, void *stream);
+ * duplicates per batch).  counter_dev (nullable): one device word added to `counter` when the kernel runs, so that a
+ * launch captured into a HIP graph draws new ids on every replay once the caller increments that word. */
+int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *counter_dev /*nullable*/, int64_t lo,
+                            int64_t hi, int N, int64_t *index, void *stream);
 
 /* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the
  * kernels rely on it being correctly rounded); n doubles, device pointers. */

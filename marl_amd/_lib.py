@@ -95,7 +95,7 @@ def load() -> C.CDLL:
     lib.asm_replay_gather_f32.restype = C.c_int
     lib.asm_replay_gather_f32.argtypes = [i32, i32, i32, i32] + [vp] * 5 + [i32] + [vp] * 5 + [vp]
     lib.asm_replay_draw_indices.restype = C.c_int
-    lib.asm_replay_draw_indices.argtypes = [u64, u32, i64, i64, i32, vp, vp]
+    lib.asm_replay_draw_indices.argtypes = [u64, u32, vp, i64, i64, i32, vp, vp]
     lib.asm_debug_sqrt_f64.restype = C.c_int
     lib.asm_debug_sqrt_f64.argtypes = [vp, vp, i32, vp]
     lib.asm_debug_cos_f32_max_err.restype = C.c_int

@@ -448,10 +448,11 @@ int asm_batch_metrics_f64(const asm_params *prm, int E, const float *p, const fl
     return rc ? hip_fail(rc, "asm_batch_metrics_f64") : 0;
 }
 
-int asm_replay_draw_indices(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *index, void *stream)
+int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *counter_dev, int64_t lo, int64_t hi, int N,
+                            int64_t *index, void *stream)
 {
     if (N < 1 || hi <= lo || !index) return fail(1, "asm_replay_draw_indices: bad arguments");
-    int rc = asmenv::launch_replay_draw(seed, counter, lo, hi, N, index, (hipStream_t)stream);
+    int rc = asmenv::launch_replay_draw(seed, counter, counter_dev, lo, hi, N, index, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_replay_draw_indices") : 0;
 }
 

@@ -72,7 +72,8 @@ int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp
                      const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
                      int *sensed, int *occupied, double *stats, hipStream_t st);
 int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int n_a, float *act, hipStream_t st);
-int launch_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *out, hipStream_t st);
+int launch_replay_draw(uint64_t seed, uint32_t counter, const uint32_t *counter_dev, int64_t lo, int64_t hi, int N, int64_t *out,
+                       hipStream_t st);
 int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ring, const float *act_ring,
                          const float *prior_ring, const float *rew_ring, const int64_t *index, int N, float *obs_out,
                          float *act_out, float *rew_out, float *next_out, float *prior_out, hipStream_t st);

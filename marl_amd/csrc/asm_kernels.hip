@@ -183,9 +183,10 @@ int launch_random_actions(uint64_t seed, uint32_t step, int64_t env0, int E, int
     return 0;
 }
 
-int launch_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *out, hipStream_t st)
+int launch_replay_draw(uint64_t seed, uint32_t counter, const uint32_t *counter_dev, int64_t lo, int64_t hi, int N, int64_t *out,
+                       hipStream_t st)
 {
-    hipLaunchKernelGGL(k_replay_draw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, seed, counter, lo, hi, N, out);
+    hipLaunchKernelGGL(k_replay_draw, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, seed, counter, counter_dev, lo, hi, N, out);
     LAUNCH_CHECK();
     return 0;
 }

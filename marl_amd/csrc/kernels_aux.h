@@ -15,10 +15,12 @@ __global__ void k_random_actions(uint64_t seed, uint32_t step, int64_t env0, int
 
 // ---- replay: uniform transition ids and the gather of sampled transitions ----------------
 // out[k] = lo + floor(u * (hi - lo)), u from two 32-bit draws of counter stream 2
-__global__ void k_replay_draw(uint64_t seed, uint32_t counter, int64_t lo, int64_t hi, int N, int64_t *out)
+// (counter_dev: optional device word added to the counter, so that a captured launch draws afresh on every replay)
+__global__ void k_replay_draw(uint64_t seed, uint32_t counter, const uint32_t *counter_dev, int64_t lo, int64_t hi, int N, int64_t *out)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
+    if (counter_dev) counter += *counter_dev;
     const uint64_t u = ((uint64_t)draw_u32(seed, (uint64_t)k, counter, 2u, 0u) << 32) | draw_u32(seed, (uint64_t)k, counter, 2u, 1u);
     out[k] = lo + (int64_t)__umul64hi(u, (uint64_t)(hi - lo));
 }

@@ -179,40 +179,47 @@ class DeviceReplay:
         return self.filled_slots * self.T * self.env.E * self.env.n_a
 
     # ---- sampling --------------------------------------------------------------------
-    def draw_indices(self, N: int) -> torch.Tensor:
-        """N transition ids, uniform over the complete slots (with replacement)."""
+    def draw_indices(self, N: int, out: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """N transition ids, uniform over the complete slots (with replacement).  counter_dev: a device int32 word
+        added to the draw counter inside the kernel (for launches captured into a HIP graph: increment it between
+        replays); `out`: where to write the ids."""
         if len(self) == 0:
             raise RuntimeError("no completed episode to sample from")
-        idx = torch.empty(N, dtype=torch.int64, device=self.env.device)
+        idx = torch.empty(N, dtype=torch.int64, device=self.env.device) if out is None else out
         with torch.cuda.device(self.env.device):
-            rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, 0, len(self), N, _ptr(idx), self.env._stream())
+            rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, _ptr(counter_dev), 0, len(self), N, _ptr(idx),
+                                                  self.env._stream())
         _lib.check(rc, "asm_replay_draw_indices")
         self.draws += 1
         slots = [k for k in range(self.S) if self.complete[k]]
         if slots != list(range(len(slots))):                        # a slot in between is being rewritten: renumber
             per_slot = self.T * self.env.E * self.env.n_a
             table = torch.tensor(slots, dtype=torch.int64, device=idx.device)
-            idx = table[idx // per_slot] * per_slot + idx % per_slot
+            remapped = table[idx // per_slot] * per_slot + idx % per_slot
+            idx = remapped if out is None else out.copy_(remapped)
         return idx
 
-    def gather(self, idx: torch.Tensor, is_prior: bool = True):
+    def gather(self, idx: torch.Tensor, is_prior: bool = True, out=None):
         """Rows of the transitions idx (int64 ids on the device): the tuple of buffer_agent.py:175-177
-        without log_pi: (obs, act, rew, next_obs, done, a_prior)."""
+        without log_pi: (obs, act, rew, next_obs, done, a_prior).  out: a tuple from an earlier call to write into."""
         e = self.env
         if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.device != self.obs_ring.device:
             raise ValueError("idx must be a contiguous int64 tensor on the environment's device")
         N, d = idx.numel(), e.obs_dim_agent
         f32 = dict(dtype=torch.float32, device=e.device)
-        obs, nxt = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
-        act, rew = torch.empty(N, 2, **f32), torch.empty(N, 1, **f32)
         want_prior = is_prior and self.prior_ring is not None
-        pri = torch.empty(N, 2, **f32) if want_prior else None
+        if out is not None:
+            obs, act, rew, nxt, done, pri = out
+        else:
+            obs, nxt = torch.empty(N, d, **f32), torch.empty(N, d, **f32)
+            act, rew = torch.empty(N, 2, **f32), torch.empty(N, 1, **f32)
+            pri = torch.empty(N, 2, **f32) if want_prior else None
+            done = torch.zeros(N, 1, **f32)                         # assembly.py:475-477: never done
         with torch.cuda.device(e.device):
             rc = self.lib.asm_replay_gather_f32(e.E, e.n_a, d, self.T, _ptr(self.obs_ring), _ptr(self.act_ring),
                                                 _ptr(self.prior_ring), _ptr(self.rew_ring), _ptr(idx), N, _ptr(obs),
                                                 _ptr(act), _ptr(rew), _ptr(nxt), _ptr(pri), e._stream())
         _lib.check(rc, "asm_replay_gather_f32")
-        done = torch.zeros(N, 1, **f32)                             # assembly.py:475-477: never done
         return obs, act, rew, nxt, done, pri
 
     def sample(self, N: int, is_prior: bool = True):

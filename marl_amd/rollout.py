@@ -69,7 +69,7 @@ class DDPGLearner:
 
     def __init__(self, obs_dim: int, act_dim: int = 2, hidden_dim: int = 256, lr_actor: float = 1e-4,
                  lr_critic: float = 1e-3, gamma: float = 0.95, tau: float = 0.01, device="cuda", act_dtype=None,
-                 data_parallel: bool = False, group=None):
+                 data_parallel: bool = False, group=None, capturable: bool = False):
         mk = lambda i, o, c: MLPNetwork(i, o, hidden_dim, c).to(device)
         self.policy, self.target_policy = mk(obs_dim, act_dim, True), mk(obs_dim, act_dim, True)
         self.critic, self.target_critic = mk(obs_dim + act_dim, 1, False), mk(obs_dim + act_dim, 1, False)
@@ -89,8 +89,8 @@ class DDPGLearner:
                     p.data.copy_(flat[off:off + p.numel()].view_as(p)); off += p.numel()
         self.target_policy.load_state_dict(self.policy.state_dict())       # agents.py:39-40
         self.target_critic.load_state_dict(self.critic.state_dict())
-        self.policy_optimizer = torch.optim.Adam(self.policy.parameters(), lr_actor)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr_critic)
+        self.policy_optimizer = torch.optim.Adam(self.policy.parameters(), lr_actor, capturable=capturable)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr_critic, capturable=capturable)
         self._pol_grads = _FlatGrads(self.policy) if self.data_parallel else None
         self._cri_grads = _FlatGrads(self.critic) if self.data_parallel else None
         self.gamma, self.tau = gamma, tau
@@ -120,9 +120,11 @@ class DDPGLearner:
         out.copy_(a.transpose(1, 2))
         return out
 
-    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True):
+    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True,
+               branch_free: bool = False):
         """maddpg.py:99-190.  Returns (critic loss, policy loss): Python floats, or 0-d tensors when
-        sync_losses=False (no host synchronisation inside the update loop)."""
+        sync_losses=False (no host synchronisation inside the update loop).  branch_free: the mask of maddpg.py:162
+        is applied as a weight instead of an index selection, so no decision is taken on the host (graph capture)."""
         if self.data_parallel:
             self._cri_grads.zero()
         else:
@@ -144,7 +146,7 @@ class DDPGLearner:
         pol_loss = -self.critic(torch.cat((obs, pol), dim=1)).mean()       # maddpg.py:153-154
         if acs_prior is not None:                                          # maddpg.py:158-174
             valid = ~(acs_prior.abs() < 1e-2).all(dim=1)
-            if self.data_parallel:                                         # no data-dependent branch: every rank runs the same ops
+            if self.data_parallel or branch_free:                          # no data-dependent branch: every rank runs the same ops
                 w = valid.to(pol.dtype).unsqueeze(1)
                 reg = ((pol - acs_prior) ** 2 * w).sum() / (w.sum() * pol.shape[1]).clamp_min(1.0)
                 pol_loss = pol_loss + 0.3 * alpha * reg
@@ -235,3 +237,72 @@ def train_phase(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
         flat = torch.stack([torch.stack(pair) for pair in losses]).cpu().tolist()
         losses = [(v, p) for v, p in flat]
     return losses
+
+
+class GraphedTrainPhase:
+    """train_assembly.py:141-157 with one update (index draw, gather, DDPG update, soft target update) captured into a
+    HIP graph and replayed num_updates times: the update is a few dozen small kernels, and launched one by one from
+    Python the 30 updates of an episode take longer than the 200 environment steps before them.
+
+    The captured draw reads its counter from a device word that is incremented inside the graph, so every replay
+    samples new transitions.  The graph is re-captured when the number of stored transitions changes (the first
+    episodes, until the replay slots are full).  Needs optimisers built with capturable=True
+    (DDPGLearner(..., capturable=True)); losses come back as a (num_updates, 2) tensor without host round trips
+    in between.  Single-rank learners only (a collective cannot be captured with the gloo rehearsal backend)."""
+
+    def __init__(self, env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceReplay, batch_size: int = 2048):
+        if learner.data_parallel:
+            raise RuntimeError("GraphedTrainPhase captures a single-rank update")
+        self.env, self.learner, self.replay, self.N = env, learner, replay, int(batch_size)
+        dev = env.device
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.idx = torch.empty(self.N, dtype=torch.int64, device=dev)
+        self.batch = None
+        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.graph, self.captured_len = None, -1
+        self.is_prior = env.training_method == "llm_rl"
+
+    def _one_update(self):
+        self.replay.draw_indices(self.N, out=self.idx, counter_dev=self.counter)
+        self.batch = self.replay.gather(self.idx, self.is_prior, out=self.batch)
+        obs, acs, rews, nxt, dones, prior = self.batch
+        vf, pl = self.learner.update(obs, acs, rews, nxt, dones, prior, self.env.alpha, sync_losses=False, branch_free=True)
+        self.losses[0].copy_(vf); self.losses[1].copy_(pl)
+        self.learner.update_all_targets()
+        self.counter.add_(1)
+
+    def _capture(self):
+        cur = torch.cuda.current_stream(self.env.device)
+        side = torch.cuda.Stream(device=self.env.device)
+        side.wait_stream(cur)
+        draws0 = self.replay.draws
+        with torch.cuda.stream(side):                               # warm-up outside the capture (allocator, lazy state of Adam)
+            for _ in range(3):
+                self._one_update()
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._one_update()
+        self.replay.draws = draws0 + 4
+        self.learner.niter -= 1                                     # capturing ran nothing
+        self.captured_len = len(self.replay)
+        return 3                                                    # updates the warm-up already did
+
+    def run(self, num_updates=None):
+        """Returns the (num_updates, 2) tensor of (critic loss, policy loss)."""
+        if num_updates is None:
+            num_updates = 30 if self.N >= 2048 else 20
+        if len(self.replay) < self.N:
+            for _ in range(num_updates):
+                self.learner.update_all_targets()                   # train_assembly.py:147-157: targets move regardless
+            return torch.zeros(0, 2)
+        out = torch.empty(num_updates, 2, dtype=torch.float32, device=self.env.device)
+        done = 0
+        if self.graph is None or self.captured_len != len(self.replay):
+            done = min(self._capture(), num_updates)
+            out[:done] = self.losses
+        for k in range(done, num_updates):
+            self.graph.replay()
+            out[k].copy_(self.losses)
+            self.learner.niter += 1
+        return out

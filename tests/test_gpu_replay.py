@@ -116,3 +116,34 @@ def test_expert_collection_fills_the_replay(torch_cuda):
     rp3 = DeviceReplay(env3, episode_length=5, slots=1)
     collect_expert_episode(env3, rp3, 5)
     assert torch.equal(env3.p, env2.p) and torch.equal(env3.obs, env2.obs)
+
+
+def test_graphed_train_phase(torch_cuda):
+    """GraphedTrainPhase: the captured update draws new transitions on every replay (device-side counter), moves the
+    weights, and counts its updates like the eager loop; with the same seed it equals the eager loop's first update."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.replay import DeviceReplay
+    from marl_amd.rollout import DDPGLearner, GraphedTrainPhase, run_episode
+    env = BatchedAssemblyEnv(16, 30, seed=2)
+    rp = DeviceReplay(env, episode_length=6, slots=2)
+    torch.manual_seed(0)
+    learner = DDPGLearner(env.obs_dim_agent, hidden_dim=32, capturable=True)
+    run_episode(env, learner, rp, 6)
+    g = GraphedTrainPhase(env, learner, rp, batch_size=256)
+    before = [p.detach().clone() for p in learner.critic.parameters()]
+    seen = []
+    losses = g.run(num_updates=3)                                   # the three warm-up updates of the capture
+    seen.append(g.idx.clone())
+    for _ in range(2):
+        losses = torch.cat([losses, g.run(num_updates=4)])
+        seen.append(g.idx.clone())
+    assert losses.shape == (11, 2) and torch.isfinite(losses).all()
+    assert learner.niter == 11 and int(g.counter.item()) == 11      # 3 warm-up updates + 8 replays (capturing runs nothing)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert int(seen[2].min()) >= 0 and int(seen[2].max()) < len(rp)
+    assert any(not torch.equal(a, b) for a, b in zip(before, learner.critic.parameters()))
+    run_episode(env, learner, rp, 6)                                # the replay grows: the graph is captured again
+    n0 = learner.niter
+    g.run(num_updates=5)
+    assert g.captured_len == len(rp) and learner.niter == n0 + 5

@@ -31,6 +31,7 @@ ap.add_argument("--episodes", type=int, default=3)
 ap.add_argument("--episode-length", type=int, default=200)
 ap.add_argument("--slots", type=int, default=2)
 ap.add_argument("--batch-size", type=int, default=2048)
+ap.add_argument("--graph", action="store_true", help="train phase as a replayed HIP graph (GraphedTrainPhase); single rank")
 ap.add_argument("--act-dtype", choices=["float32", "bfloat16"], default="float32", help="rollout inference precision")
 a = ap.parse_args()
 
@@ -54,21 +55,30 @@ torch.manual_seed(rank)
 env = BatchedAssemblyEnv(a.envs, a.agents, device=device, env_id_offset=shard_range(rank, world, a.envs)[0])
 rp = DeviceReplay(env, a.episode_length, a.slots, seed=rank)
 learner = DDPGLearner(env.obs_dim_agent, device=device, act_dtype=torch.bfloat16 if a.act_dtype == "bfloat16" else None,
-                      data_parallel=world > 1)
+                      data_parallel=world > 1, capturable=a.graph)
+graphed = None
+if a.graph:
+    from marl_amd.rollout import GraphedTrainPhase
+    graphed = GraphedTrainPhase(env, learner, rp, a.batch_size)
 run_episode(env, learner, rp, a.episode_length if a.episode_length < 5 else 5)      # warm-up: kernels loaded, allocator primed
 rp.slot, rp.t, rp.filled_slots = -1, 0, 0
 gather_s = train_time = roll_time = 0.0
+train_each = []
 stats = None
 for ep in range(a.episodes):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     stats = summarize(run_episode(env, learner, rp, a.episode_length), a.agents)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    train_phase(env, learner, rp, a.batch_size)
+    if graphed is not None:
+        graphed.run()
+    else:
+        train_phase(env, learner, rp, a.batch_size)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     for _ in range(30):                                                # the sampler alone, same count as the phase above
         rp.sample(a.batch_size)
     torch.cuda.synchronize(); t3 = time.perf_counter()
     roll_time += t1 - t0; train_time += t2 - t1; gather_s += t3 - t2
+    train_each.append(t2 - t1)
 if world > 1:
     t = torch.tensor([roll_time, train_time, gather_s], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -79,11 +89,13 @@ if rank == 0:
         "workload": f"{a.envs} envs x {a.agents} agents per GPU x {world} GPU(s), {a.episodes} episodes of {a.episode_length} steps, "
                     f"policy/critic MLP 256, 30 updates of {a.batch_size} per episode and rank, replay in HBM "
                     f"({a.slots} episode slots), rollout inference in {a.act_dtype}"
-                    + (", learner replicas with averaged gradients" if world > 1 else ""),
+                    + (", learner replicas with averaged gradients" if world > 1 else "")
+                    + (", train phase replayed from a HIP graph" if a.graph else ""),
         "n_gpus": world,
         "rollout_agent_steps_per_s": world * a.envs * a.agents * steps / roll_time,
         "rollout_ms_per_step": roll_time / steps * 1e3,
         "train_phase_s_per_episode": train_time / a.episodes,
+        "train_phase_s_each_episode": train_each,                     # the first episodes include HIP-graph captures (--graph)
         "sampler_s_per_episode_30_batches": gather_s / a.episodes,
         "env_episodes_per_s_end_to_end": world * a.envs * a.episodes / (roll_time + train_time),
         "replay_bytes_per_gpu": sum(t.numel() * 4 for t in (rp.obs_ring, rp.act_ring, rp.prior_ring, rp.rew_ring) if t is not None),
