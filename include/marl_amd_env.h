@@ -123,6 +123,10 @@ void asm_default_params(asm_params *prm, int n_a, int n_g_max);
 int asm_obs_dim(const asm_params *prm);
 
 int asm_abi_version(void);
+/* Tuning / test knob: which kernel asm_batch_*_f32 runs for environments of at most 32 agents: 4 (default), 2 or 1
+ * wavefronts per workgroup of the multi-wave step kernel, 0 = the generic kernel, -1 = back to the default (the
+ * MARL_AMD_FAST_T environment variable, read once per process, else 4).  All produce the same results. */
+void asm_set_step_schedule(int waves);
 const char *asm_last_error(void);
 /* Number of visible HIP devices, or a negative HIP error code. */
 int asm_device_count(void);
@@ -304,6 +308,11 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
  * launch captured into a HIP graph draws new ids on every replay once the caller increments that word. */
 int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *counter_dev /*nullable*/, int64_t lo,
                             int64_t hi, int N, int64_t *index, void *stream);
+
+/* Self-test hook: which kernel asm_batch_step_f32 would launch for these arguments: waves per workgroup of the
+ * multi-wave kernel (4, 2, 1) or 0 for the generic kernel, plus 16 if its lattice path is taken, plus 32 if the
+ * generic kernel's (large swarms); negative on bad arguments.  Host-side only. */
+int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lattice /*nullable*/);
 
 /* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the
  * kernels rely on it being correctly rounded); n doubles, device pointers. */

@@ -125,6 +125,11 @@ class BatchedAssemblyEnv:
     def _lat(self):
         return C.byref(self._lattice) if (self._lattice is not None and self.lattice_valid) else None
 
+    def step_schedule(self) -> int:
+        """Which kernel step() launches now (asm_debug_step_schedule): waves per workgroup of the multi-wave kernel or
+        0 for the generic one, + 16 with its lattice path, + 32 with the generic kernel's lattice path."""
+        return self.lib.asm_debug_step_schedule(C.byref(self.params), self.E, self._lat())
+
     def invalidate_lattice(self) -> None:
         """Call after writing grid_center / n_g / shape_id / xform directly: the kernels then test every cell against
         every agent (the grids no longer follow the lattice description) until the next reset() or set_shape()."""

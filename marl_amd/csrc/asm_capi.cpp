@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "asm_kernels.h"
@@ -57,10 +58,13 @@ double thr_le(double t)
 int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // MARL_AMD_FAST_T (tuning / test knob: waves per workgroup of k_step_fast, 0 = generic kernel), read once per process
+// asm_set_step_schedule() overrides it at run time (tests compare the schedules within one process).
+std::atomic<int> g_schedule_override{-1};
 int fast_t_setting()
 {
     static const int v = [] { const char *ov = std::getenv("MARL_AMD_FAST_T"); return ov ? std::atoi(ov) : 4; }();
-    return v;
+    const int o = g_schedule_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : v;
 }
 
 // Launch geometry + thresholds.  state_bytes = sizeof(S).
@@ -70,20 +74,21 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
 // (parameters, E) combinations over and over, so the last results are kept per thread.
 int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out)
 {
-    struct Slot { asm_params prm; int E; size_t sb; DevParams P; bool used; };
+    struct Slot { asm_params prm; int E; size_t sb; int sched; DevParams P; bool used; };
     constexpr int N = 8;
     thread_local Slot cache[N];
     thread_local int next = 0;
     static const bool no_cache = std::getenv("MARL_AMD_NO_PARAM_CACHE") != nullptr;   // measurement knob (tools/host_launch_cost.py)
     if (prm && !no_cache)
         for (int k = 0; k < N; ++k)
-            if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && !std::memcmp(&cache[k].prm, prm, sizeof *prm)) {
+            if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && cache[k].sched == fast_t_setting() &&
+                !std::memcmp(&cache[k].prm, prm, sizeof *prm)) {
                 *out = cache[k].P;
                 return 0;
             }
     if (int rc = derive_dev_params(prm, E, state_bytes, out)) return rc;
     Slot &s = cache[next]; next = (next + 1) % N;
-    std::memcpy(&s.prm, prm, sizeof *prm); s.E = E; s.sb = state_bytes; s.P = *out; s.used = true;
+    std::memcpy(&s.prm, prm, sizeof *prm); s.E = E; s.sb = state_bytes; s.sched = fast_t_setting(); s.P = *out; s.used = true;
     return 0;
 }
 
@@ -329,6 +334,7 @@ int asm_obs_dim(const asm_params *p)
 }
 
 int asm_abi_version(void) { return ASM_ABI_VERSION; }
+void asm_set_step_schedule(int waves) { g_schedule_override.store(waves, std::memory_order_relaxed); }
 const char *asm_last_error(void) { return g_err; }
 
 int asm_device_count(void)
@@ -476,6 +482,16 @@ int asm_batch_check_lattice(const asm_params *prm, int E, const float *grid, con
     asmenv::LatArgs LA{lattice->shapes, lattice->shape_id, lattice->xform, lattice->n_shapes};
     int rc = asmenv::launch_check_lattice(E, prm->n_g_max, grid, n_g, LA, tol, n_bad, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_batch_check_lattice") : 0;
+}
+
+int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lattice)
+{
+    DevParams P;
+    if (make_dev_params(prm, E, sizeof(float), &P)) return -1;
+    asmenv::LatArgs LA{};
+    if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
+    else lattice_usable_swarm(lattice, prm, &P, &LA);
+    return P.fast_T + 16 * P.lat;
 }
 
 #ifdef ASM_DIAG

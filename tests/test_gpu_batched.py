@@ -12,6 +12,26 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ROLLOUTS = sorted(glob.glob(os.path.join(GOLDEN, "rollout_*.npz")))
 
 
+_RESET = []
+
+
+def _schedule(monkeypatch, waves):
+    """Select the step kernel's schedule for this test (asm_set_step_schedule); the fixture below restores the
+    default afterwards.  (The MARL_AMD_FAST_T variable is read once per process, so it cannot switch schedules
+    between tests.)"""
+    from marl_amd import _lib
+    lib = _lib.load()
+    lib.asm_set_step_schedule(int(waves))
+    _RESET.append(lib)
+
+
+@pytest.fixture(autouse=True)
+def _default_schedule_after_each_test():
+    yield
+    while _RESET:
+        _RESET.pop().asm_set_step_schedule(-1)
+
+
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
@@ -114,7 +134,7 @@ def test_kernel_schedules_against_oracle(torch_cuda, monkeypatch, fast_t):
     """The generic kernel (0) and the multi-wave kernel at 1, 2 and 4 waves per workgroup,
     each checked against the oracle in the packed-inside-the-shape regime."""
     torch = torch_cuda
-    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    _schedule(monkeypatch, fast_t)
     from marl_amd.batched import BatchedAssemblyEnv
     from gpu_util import cfg_from_env, check_observation, teacher_forced_step
     E, n_a = 21, 30
@@ -138,9 +158,10 @@ def test_kernel_schedules_agree_bit_for_bit(torch_cuda, monkeypatch):
     E, n_a, steps = 301, 30, 12
     outs = {}
     for fast_t in ("0", "1", "2", "4"):
-        monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+        _schedule(monkeypatch, fast_t)
         env = BatchedAssemblyEnv(E, n_a, seed=3, keep_indices=True)
         env.reset()
+        assert env.step_schedule() == int(fast_t) + (16 if fast_t == "4" else 0)      # the kernel asked for is the one that runs
         rec = []
         for t in range(steps):
             obs, rew, _, _, prior = env.step(env.random_actions())
@@ -464,7 +485,7 @@ def test_lattice_states_full_of_ties(torch_cuda, monkeypatch, n_a, step_denomina
     exception.  Observation and teacher-forced steps against the oracle, indices exact (fast_t: the kernel
     schedule, "0" = the generic kernel)."""
     torch = torch_cuda
-    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    _schedule(monkeypatch, fast_t)
     from marl_amd.batched import BatchedAssemblyEnv
     from gpu_util import cfg_from_env, check_observation, teacher_forced_step
     E = 12
@@ -528,7 +549,7 @@ def test_other_list_capacities(torch_cuda, monkeypatch, cap, occ_cap, fast_t):
     ranges per wave, sub-sampling and the observation layout all follow the capacity.  An odd capacity is served
     by the generic kernel."""
     torch = torch_cuda
-    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    _schedule(monkeypatch, fast_t)
     from marl_amd.batched import BatchedAssemblyEnv
     from gpu_util import cfg_from_env, check_observation, teacher_forced_step
     E, n_a = 10, 30
@@ -551,7 +572,7 @@ def test_non_default_physics(torch_cuda, monkeypatch, fast_t):
     """Every scalar of asm_params away from the reference's default (mass != 1 takes the division of
     assembly.py:638): dynamics, prior and observation against the oracle configured alike."""
     torch = torch_cuda
-    monkeypatch.setenv("MARL_AMD_FAST_T", fast_t)
+    _schedule(monkeypatch, fast_t)
     from marl_amd.batched import BatchedAssemblyEnv
     from gpu_util import cfg_from_env, check_observation, teacher_forced_step
     E, n_a = 8, 30
@@ -604,7 +625,7 @@ def test_periodic_arena_kernels_agree(torch_cuda, monkeypatch):
     E, n_a, steps = 64, 30, 40
     outs = {}
     for mode in ("4", "0"):
-        monkeypatch.setenv("MARL_AMD_FAST_T", mode)
+        _schedule(monkeypatch, mode)
         env = BatchedAssemblyEnv(E, n_a, seed=91, is_boundary=False, keep_indices=True)
         env.reset()
         p = env.p.clone()

@@ -37,6 +37,7 @@ def test_lattice_path_equals_all_cells_path_random_regime(torch_cuda):
     a, b = _pair(1501)
     a.reset(); b.reset()
     assert a.lattice_valid and not b.lattice_valid
+    assert a.step_schedule() == 4 + 16 and b.step_schedule() == 4
     _same(torch, a, b, "reset")
     for t in range(40):
         act = a.random_actions(step=t)
@@ -136,6 +137,7 @@ def test_lattice_path_large_swarms(torch_cuda, n_a, E):
     from gpu_util import cfg_from_env, teacher_forced_step
     a, b = _pair(E, n_a=n_a, seed=n_a)
     a.reset(); b.reset()
+    assert a.step_schedule() == 32 and b.step_schedule() == 0
     for t in range(3):
         act = a.random_actions(step=t)
         a.step(act); b.step(act)

@@ -8,7 +8,8 @@ from marl_amd.batched import BatchedAssemblyEnv
 E, n_a = 21, 30
 res = {}
 for T in sys.argv[1:] or ["0", "1"]:
-    os.environ["MARL_AMD_FAST_T"] = T
+    from marl_amd import _lib
+    _lib.load().asm_set_step_schedule(int(T))
     env = BatchedAssemblyEnv(E, n_a, seed=11, keep_indices=True)
     env.reset()
     rng = np.random.default_rng(4)

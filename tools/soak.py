@@ -19,7 +19,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 
 
 def make(T):
-    os.environ["MARL_AMD_FAST_T"] = T
+    from marl_amd import _lib
+    _lib.load().asm_set_step_schedule(int(T))
     return BatchedAssemblyEnv(E, 30, seed=5, keep_indices=True)
 
 
