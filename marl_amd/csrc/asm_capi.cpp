@@ -168,13 +168,13 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
 }
 
 // The lattice path of k_step_fast: decides whether this call may use it and fills the kernel's view of it.
-// Conditions: the 4-wave schedule with walls; the tables fit the unused part of the kernel's grid area in LDS;
+// Conditions: the 4-wave schedule; the tables fit the unused part of the kernel's grid area in LDS;
 // the sensing disc fits the kernel's window of 15 lattice rows x 15 columns and the occupancy disc 7 x 7.
 bool lattice_usable(const asm_lattice *lat, const asm_params *prm, DevParams *P, asmenv::LatArgs *out)
 {
     P->lat = 0;
     if (!lat || !lat->shapes || !lat->shape_id || !lat->xform || lat->n_shapes < 1 || !(lat->l_cell_min > 0)) return false;
-    if (P->fast_T != 4 || P->periodic) return false;
+    if (P->fast_T != 4) return false;                                   // (the cell computations are never wrapped: either arena)
     const size_t table_floats = 2 * sizeof(uint32_t) * (ASM_LAT_ROWS * ASM_LAT_CHUNKS * 2) / 4 + 2 * sizeof(uint16_t) * ASM_LAT_NB / 4;
     if (2 * (size_t)P->NGP + 64 + table_floats > ASM_GY_OFF) return false;
     const double R = prm->d_sen / lat->l_cell_min, Ro = prm->r_avoid / 2.0 / lat->l_cell_min;

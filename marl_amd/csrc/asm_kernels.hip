@@ -103,7 +103,7 @@ static int launch_step_fast_t(const DevParams &P, const LatArgs &lat, float *p, 
         LAUNCH_CHECK();
         return 0;
     };
-    if constexpr (T == 4 && !PER)                                   // the lattice path exists for this schedule only
+    if constexpr (T == 4)                                           // the lattice path exists for this schedule only
         if (P.lat)
             return occupied ? go(k_step_fast<T, PER, 2, true>) : sensed ? go(k_step_fast<T, PER, 1, true>) : go(k_step_fast<T, PER, 0, true>);
     return occupied ? go(k_step_fast<T, PER, 2, false>) : sensed ? go(k_step_fast<T, PER, 1, false>) : go(k_step_fast<T, PER, 0, false>);

@@ -155,3 +155,30 @@ def test_lattice_path_large_swarms(torch_cuda, n_a, E):
         b.step(torch.from_numpy(act).cuda())
         _same(torch, a, b, f"swarm packed {t}")
     assert torch.allclose(a.stats, b.stats, rtol=1e-12, atol=0)
+
+
+def test_lattice_path_periodic_arena(torch_cuda):
+    """is_boundary=False (no walls, wrapped positions and neighbour offsets; the cell computations are never wrapped,
+    AssemblyEnv.cpp:93-95 vs 863-913): lattice path on, against the all-cells path and the oracle."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, teacher_forced_step
+    E, n_a = 65, 30
+    a, b = _pair(E, seed=21, is_boundary=False)
+    a.reset(); b.reset()
+    assert a.step_schedule() == 4 + 16 and b.step_schedule() == 4
+    cfg = cfg_from_env(a)
+    rng = np.random.default_rng(2)
+    for t in range(12):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        teacher_forced_step(a, cfg, act, f"periodic lattice {t}")
+        b.step(torch.from_numpy(act).cuda())
+        _same(torch, a, b, f"periodic {t}")
+    grid = a.grid_center.cpu().numpy(); n_g = a.n_g.cpu().numpy()
+    p = np.stack([grid[e][:, rng.choice(n_g[e], n_a, replace=False)] + rng.normal(0, 0.02, (2, n_a)) for e in range(E)]).astype(np.float32)
+    for env in (a, b):
+        env.p.copy_(torch.from_numpy(p)); env.observe()
+    for t in range(6):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        teacher_forced_step(a, cfg, act, f"periodic packed lattice {t}")
+        b.step(torch.from_numpy(act).cuda())
+        _same(torch, a, b, f"periodic packed {t}")
