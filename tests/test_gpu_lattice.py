@@ -182,3 +182,32 @@ def test_lattice_path_periodic_arena(torch_cuda):
         teacher_forced_step(a, cfg, act, f"periodic packed lattice {t}")
         b.step(torch.from_numpy(act).cuda())
         _same(torch, a, b, f"periodic packed {t}")
+
+
+@pytest.mark.parametrize("n_a,kw,on", [(30, dict(d_sen=0.3), True), (30, dict(d_sen=0.42, r_avoid=0.2), True),
+                                       (20, {}, True), (16, {}, True), (30, dict(d_sen=0.46), False), (10, {}, False),
+                                       (30, dict(num_obs_grid_max=30, num_occupied_grid_max=40), True)])
+def test_lattice_path_other_radii(torch_cuda, n_a, kw, on):
+    """Sensing and avoidance radii other than the defaults: the lattice window (15 x 15 sites for d_sen, 7 x 7 for
+    r_avoid / 2) covers d_sen <= 7.4 l_cell and r_avoid / 2 <= 3.4 l_cell; beyond that the call falls back to testing
+    every cell by itself.  Either way: equal to the all-cells path and to the oracle."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, teacher_forced_step
+    E = 40
+    a, b = _pair(E, n_a=n_a, seed=31, **kw)
+    a.reset(); b.reset()
+    assert a.step_schedule() == (4 + 16 if on else 4), (a.r_avoid, a.params.d_sen)
+    cfg = cfg_from_env(a)
+    rng = np.random.default_rng(5)
+    grid = a.grid_center.cpu().numpy(); n_g = a.n_g.cpu().numpy()
+    p = a.p.cpu().numpy()
+    for e in range(0, E, 2):                                         # every other environment packed into its shape
+        p[e] = grid[e][:, rng.choice(n_g[e], n_a, replace=False)] + rng.normal(0, 0.03, (2, n_a))
+    for env in (a, b):
+        env.p.copy_(torch.from_numpy(p)); env.observe()
+    _same(torch, a, b, "observe")
+    for t in range(6):
+        act = rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)
+        teacher_forced_step(a, cfg, act, f"radii {kw} step {t}")
+        b.step(torch.from_numpy(act).cuda())
+        _same(torch, a, b, f"step {t}")
