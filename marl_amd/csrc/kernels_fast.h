@@ -885,6 +885,12 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const int own = (2 - es) * NGP + l;                     // an empty slot reads the lane's own position: x - x = +0 (CPP:329-333 zeros)
             const f32x2 p2 = {pxf, pyf};
             for (int kb = k0; kb < k1; kb += RB) {
+                if (__ballot(kb < n_out) == 0) {                    // no list of the wave's agents reaches this round: rows of +0
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (kb + q < k1) { ostore(gb + 2 * (kb + q), 0.f); ostore(gb + 2 * (kb + q) + 1, 0.f); }
+                    continue;
+                }
                 int cell[RB]; f32x2 c2[RB]; bool have[RB];
 #pragma unroll
                 for (int q = 0; q < RB; ++q) cell[q] = mysel[kb + q];   // one batch of LDS reads; entries past k1 (the list is padded by RB) are masked below

@@ -19,6 +19,15 @@ from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n_a = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+# third argument "2": a second batch of the same size is stepped on another stream all the time (the steady state of
+# the two-shard benchmark); its workgroups stamp into the same buffer, so the numbers are a mix of both launches
+other = None
+if len(sys.argv) > 3 and sys.argv[3] == "2":
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        other = BatchedAssemblyEnv(E, n_a, env_id_offset=E)
+        other.reset()
+        other_act = other.random_actions()
 env = BatchedAssemblyEnv(E, n_a)
 lib = env.lib
 env.reset()
@@ -30,7 +39,14 @@ assert lib.asm_diag_set_buffer(C.c_void_p(buf.data_ptr())) == 0
 acc = None
 for t in range(10):
     buf.zero_()
-    env.step(env.random_actions())
+    act = env.random_actions()
+    torch.cuda.synchronize()
+    if other is not None:
+        for _ in range(3):
+            other.step(other_act, side.cuda_stream)
+            env.step(act)
+    else:
+        env.step(act)
     torch.cuda.synchronize()
     b = buf.cpu().numpy()
     b = b[b[:, 9] > 0]
