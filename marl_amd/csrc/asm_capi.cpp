@@ -59,13 +59,16 @@ int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // MARL_AMD_FAST_T (tuning / test knob: waves per workgroup of k_step_fast, 0 = generic kernel), read once per process
 // asm_set_step_schedule() overrides it at run time (tests compare the schedules within one process).
+// Bit 4 of the value (+16): the large-swarm pair passes without their cell lists.
 std::atomic<int> g_schedule_override{-1};
-int fast_t_setting()
+int schedule_setting()
 {
     static const int v = [] { const char *ov = std::getenv("MARL_AMD_FAST_T"); return ov ? std::atoi(ov) : 4; }();
     const int o = g_schedule_override.load(std::memory_order_relaxed);
     return o >= 0 ? o : v;
 }
+int fast_t_setting() { return schedule_setting() & 15; }
+bool cell_lists_off() { return (schedule_setting() & 16) != 0; }
 
 // Launch geometry + thresholds.  state_bytes = sizeof(S).
 int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out);
@@ -81,14 +84,14 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     static const bool no_cache = std::getenv("MARL_AMD_NO_PARAM_CACHE") != nullptr;   // measurement knob (tools/host_launch_cost.py)
     if (prm && !no_cache)
         for (int k = 0; k < N; ++k)
-            if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && cache[k].sched == fast_t_setting() &&
+            if (cache[k].used && cache[k].E == E && cache[k].sb == state_bytes && cache[k].sched == schedule_setting() &&
                 !std::memcmp(&cache[k].prm, prm, sizeof *prm)) {
                 *out = cache[k].P;
                 return 0;
             }
     if (int rc = derive_dev_params(prm, E, state_bytes, out)) return rc;
     Slot &s = cache[next]; next = (next + 1) % N;
-    std::memcpy(&s.prm, prm, sizeof *prm); s.E = E; s.sb = state_bytes; s.sched = fast_t_setting(); s.P = *out; s.used = true;
+    std::memcpy(&s.prm, prm, sizeof *prm); s.E = E; s.sb = state_bytes; s.sched = schedule_setting(); s.P = *out; s.used = true;
     return 0;
 }
 
@@ -161,6 +164,31 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
                                  std::max({2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW,
                                            (size_t)(4 * 4 * ASM_LAT_NB + 4 * 64 * (ASM_LAT_NB / 32))});   // lattice path: compact boundary coordinates + word keys
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
+        }
+    }
+    // Large swarms (one environment per workgroup, walls, fp32 state): cell lists for the two pair passes.  They live in
+    // the per-agent mask area of the environment's LDS block, which is idle until the cell pass: bin counters / starts
+    // (one word per bin + 1, + 16 wave totals), then position pairs and 16-bit indices in bin order.
+    P.bins = 0;
+    if (state_bytes == 4 && !P.periodic && P.EPB == 1 && P.SL >= 256 && !cell_lists_off()) {
+        const size_t region = 4 * (size_t)P.SL * P.MW;
+        auto geom = [&](double radius, int max_reach, asmenv::BinGeom *G) {
+            const double r = radius * 1.001;                        // covers the screens' inflated thresholds and the rounding of the bin coordinates
+            double h = r / max_reach;
+            for (int it = 0; it < 400; ++it, h *= 1.05) {
+                const double nx = std::ceil(2 * P.half_w / h), ny = std::ceil(2 * P.half_h / h);
+                if (!(nx >= 1 && ny >= 1) || nx * ny > 60000) continue;
+                const size_t need = 4 * ((size_t)(nx * ny) + 1 + 16 + 1) + 10 * (size_t)P.SL;
+                if (need > region) continue;
+                G->nbx = (int)nx; G->nby = (int)ny; G->inv_h = (float)(1.0 / h);
+                G->reach = (int)std::ceil(r / h);
+                return true;
+            }
+            return false;
+        };
+        static const int reach_s = [] { const char *v = std::getenv("MARL_AMD_BIN_REACH"); const int r = v ? std::atoi(v) : 3; return r < 1 ? 1 : (r > 8 ? 8 : r); }();
+        if (P.half_w > 0 && P.half_h > 0 && P.sizes2 > 0 && P.d_sen > 0 && geom(P.sizes2, 1, &P.bin_c) && geom(P.d_sen, reach_s, &P.bin_s)) {
+            P.bins = 1; P.bin_x0 = (float)P.half_w; P.bin_y0 = (float)P.half_h;
         }
     }
     *out = P;
@@ -491,7 +519,7 @@ int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lat
     asmenv::LatArgs LA{};
     if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
     else lattice_usable_swarm(lattice, prm, &P, &LA);
-    return P.fast_T + 16 * P.lat;
+    return P.fast_T + 16 * P.lat + 64 * P.bins;
 }
 
 #ifdef ASM_DIAG

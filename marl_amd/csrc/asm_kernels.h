@@ -17,6 +17,11 @@ namespace asmenv {
 
 constexpr int ASM_MAX_AGENTS = 1024;   // largest n_a the entry points accept
 
+// Cell list over the arena (large swarms): nbx x nby square bins of side 1 / inv_h counted from the arena's lower left
+// corner (positions outside fall into the border bins); two agents closer than the radius the list was sized for lie
+// at most `reach` bins apart in either direction.
+struct BinGeom { int nbx, nby, reach; float inv_h; };
+
 // Kernel parameters, passed by value.  The T_* members are squared-distance
 // thresholds: for a threshold t of the reference, T = min{ s : fl(sqrt(s)) >= t } so that
 // fl(sqrt(s)) < t  <=>  s < T exactly (T_*_le: min{ s : fl(sqrt(s)) > t }, so that
@@ -34,6 +39,9 @@ struct DevParams {
     unsigned fast_lds_bytes;
     int lat, lat_KO;                // lattice path: 0 off, 1 k_step_fast, 2 k_step (large swarms); lattice rows |k| <= lat_KO can hold an occupied cell
     float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)
+    int bins;                       // large swarms: the pair passes (contacts, k nearest neighbours) go through cell lists
+    BinGeom bin_c, bin_s;           // ... sized for the contact distance and for the sensing radius
+    float bin_x0, bin_y0;           // half_w, half_h in single precision
     double T_sen;                   // norm < d_sen            CPP:663, 907
     double T_half_le;               // !(norm > r_avoid/2)     CPP:190
     double T_half_lt;               // norm < r_avoid/2        WRAP:67

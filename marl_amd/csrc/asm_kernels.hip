@@ -131,6 +131,10 @@ int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float
                 const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
                 int *occupied, double *stats, hipStream_t st)
 {
+#ifdef ASM_EXITS
+    { const char *x = std::getenv("MARL_AMD_DBG_EXIT"); const int v = x ? std::atoi(x) : 0;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
+#endif
     if (int rc = set_lds(k_step<S>, P.lds_block_bytes)) return rc;
     hipLaunchKernelGGL(k_step<S>, dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, lat, p, dp, act, grid, n_g, l_cell,
                        nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);

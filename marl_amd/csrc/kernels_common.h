@@ -179,6 +179,77 @@ __device__ __forceinline__ unsigned pair_screen32(const float *X, const float *Y
     return __brev(m);
 }
 
+// ---- cell list of one environment's agents (large swarms; one environment per workgroup) ----
+// Agents in bin order (row-major bins): start[b] .. start[b + 1] are the places of bin b's agents in pos / idx; the
+// order inside a bin is whatever the counting pass produced, so users must not depend on it.
+struct BinView {
+    unsigned *start;               // [nbx * nby + 1] (+ 16 wave totals used while building)
+    f32x2 *pos;                    // [SL]
+    unsigned short *idx;           // [SL]
+};
+
+__device__ __forceinline__ BinView bins_carve(unsigned *region, const BinGeom &G, int SL)
+{
+    BinView B;
+    const int nb1 = G.nbx * G.nby + 1;
+    B.start = region;
+    B.pos = reinterpret_cast<f32x2 *>(region + ((nb1 + 16 + 1) & ~1));
+    B.idx = reinterpret_cast<unsigned short *>(B.pos + SL);
+    return B;
+}
+
+__device__ __forceinline__ int bin_coord(float x, float x0, float inv_h, int nb)
+{
+    const float v = __builtin_fminf(__builtin_fmaxf((x + x0) * inv_h, 0.f), (float)(nb - 1));    // NaN -> 0
+    return (int)v;
+}
+
+// Builds the list for the positions (x, y) of the workgroup's agents.  Reached by every thread; five barriers, the
+// first of which also orders this build after whatever used the region before.
+__device__ __forceinline__ void bins_build(const DevParams &P, const BinGeom &G, const BinView &B, int i, bool active, float x, float y)
+{
+    const int SL = P.SL, nb1 = G.nbx * G.nby + 1;
+    __syncthreads();
+    for (int k = i; k < nb1 + 16; k += SL) B.start[k] = 0;
+    __syncthreads();
+    int b = 0; unsigned rank = 0;
+    if (active) {
+        b = bin_coord(y, P.bin_y0, G.inv_h, G.nby) * G.nbx + bin_coord(x, P.bin_x0, G.inv_h, G.nbx);
+        rank = atomicAdd(&B.start[b], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum in place: thread i owns C consecutive counters (C odd: conflict-free strides)
+    const int C = ((nb1 + SL - 1) / SL) | 1, k0 = i * C;
+    unsigned sum = 0;
+    for (int k = 0; k < C; ++k) if (k0 + k < nb1) sum += B.start[k0 + k];
+    unsigned incl = sum;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const unsigned t = __shfl_up(incl, m, 64); if ((i & 63) >= m) incl += t; }
+    unsigned *wtot = B.start + nb1;
+    if ((i & 63) == 63) wtot[i >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < (i >> 6); ++w) run += wtot[w];
+    for (int k = 0; k < C; ++k) if (k0 + k < nb1) { const unsigned c = B.start[k0 + k]; B.start[k0 + k] = run; run += c; }
+    __syncthreads();
+    if (active) { const unsigned at = B.start[b] + rank; const f32x2 q = {x, y}; B.pos[at] = q; B.idx[at] = (unsigned short)i; }
+    __syncthreads();
+}
+
+// f(position, index) for every listed agent within `reach` bins of (x, y), row of bins by row.
+template <typename F>
+__device__ __forceinline__ void bins_for_each(const DevParams &P, const BinGeom &G, const BinView &B, float x, float y, F f)
+{
+    const int bx = bin_coord(x, P.bin_x0, G.inv_h, G.nbx), by = bin_coord(y, P.bin_y0, G.inv_h, G.nby);
+    const int xa = bx - G.reach > 0 ? bx - G.reach : 0, xb = bx + G.reach < G.nbx - 1 ? bx + G.reach : G.nbx - 1;
+    const int ya = by - G.reach > 0 ? by - G.reach : 0, yb = by + G.reach < G.nby - 1 ? by + G.reach : G.nby - 1;
+    for (int r = ya; r <= yb; ++r) {
+        unsigned t = B.start[r * G.nbx + xa];
+        const unsigned hi = B.start[r * G.nbx + xb + 1];
+        for (; t < hi; ++t) f(B.pos[t], (int)B.idx[t]);
+    }
+}
+
 // Occupancy (CPP:190, !(norm > r_avoid/2)) and coverage (WRAP:67, norm < r_avoid/2) bits of one agent for
 // one 32-cell word, OR-ed into the environment's bitmaps.  `oc` is the single-precision screen s32 < T_half;
 // it is exact for both tests unless some cell lies within the margin of the threshold (smallest |s32 - T_half|

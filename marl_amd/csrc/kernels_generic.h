@@ -18,11 +18,24 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
 {
     constexpr bool F32 = sizeof(S) == 4;
     const int n_a = P.n_a;
+#ifdef ASM_EXITS
+    const int xat = g_exit_at;
+#endif
     // large swarms on fp32 state: pair loops screen 32 agents at a time, the cell pass settles undecided words only
     const bool swarm = F32 && !P.periodic && P.SL >= 64;
     const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
     const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
     S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
+    // cell list of the agents for the neighbour search (in the mask area, which the cell pass takes over afterwards)
+    [[maybe_unused]] BinView BVs;
+    [[maybe_unused]] const BinView *BV = nullptr;
+    if constexpr (F32) {
+        if (swarm && P.bins) {
+            BVs = bins_carve(L.mask, P.bin_s, P.SL);
+            bins_build(P, P.bin_s, BVs, i, active, (float)L.px[i], (float)L.py[i]);
+            BV = &BVs;
+        }
+    }
 
     // ---- k nearest neighbours inside d_sen: _get_focused, CPP:633-703 ----
     double s6[6]; int j6[6];
@@ -45,9 +58,21 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 // the low 10 bits replaced by the index) that keeps the 7 smallest.  The list is read off the keys
                 // when every neighbouring pair differs by at least two units of 1024 ulps and every listed key lies
                 // two units below T_sen; otherwise this agent redoes its list with exact double insertion.
+                // The candidates come from the cell list when there is one (any order: the keys are distinct),
+                // else from screens of 32 agents at a time.
                 unsigned K[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
+                if (BV)
+                    bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
+                        const float rx = c.x - pxf, ry = c.y - pyf, s32 = __builtin_fmaf(ry, ry, rx * rx);
+                        if (s32 < P.Tsen_hi_f && j != i) {                              // self removed CPP:677-681
+                            unsigned x = (__float_as_uint(s32) & ~1023u) | (unsigned)j;
+#pragma unroll
+                            for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                        }
+                    });
+                else
                 for (int j0 = 0; j0 < P.SL; j0 += 32) {
                     unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
                     if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));        // self removed CPP:677-681
@@ -68,7 +93,25 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                     redo |= there && (u >= tlo || (K[q + 1] >> 10) - u < 2u);
                     j6[q] = there ? (int)(K[q] & 1023u) : -1;
                 }
-                if (redo) {                                                     // rare
+                if (redo && BV) {                                               // rare; candidates in any order: (s, j) decides
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) j6[q] = -1;
+                    bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
+                        const float rx = c.x - pxf, ry = c.y - pyf;
+                        if (__builtin_fmaf(ry, ry, rx * rx) < P.Tsen_hi_f && j != i) {
+                            const double dx = (double)c.x - px, dy = (double)c.y - py;
+                            const double s = dx * dx + dy * dy;                 // CPP:641
+                            if (s < P.T_sen) {                                  // CPP:663
+                                double ks = s; int kj = j; bool placed = false;
+#pragma unroll
+                                for (int q = 0; q < 6; ++q)
+                                    if (placed || ks < s6[q] || (ks == s6[q] && kj < j6[q])) {
+                                        const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true;
+                                    }
+                            }
+                        }
+                    });
+                } else if (redo) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) j6[q] = -1;
                     for (int j0 = 0; j0 < P.SL; j0 += 32) {
@@ -142,6 +185,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     STAMP(4);
+    EXIT_AT(3);
     // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
     for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
     __syncthreads();
@@ -164,6 +208,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
     }
     STAMP(5);
+    EXIT_AT(4);
     const double dmin = sqrt(smin);
     const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
     __syncthreads();
@@ -200,6 +245,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     STAMP(6);
+    EXIT_AT(5);
     // ---- sensed list (CPP:243-296) and exploration reward terms (CPP:499-557) ----
     // psi = rho_cos_dec(z, 0, d_sen), CPP:1017-1025
     auto psi_exact = [&](double gx, double gy) {
@@ -263,6 +309,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     STAMP(7);
+    EXIT_AT(6);
     // ---- reward: CPP:457-564 ----
     double reward = 0.0;
     if (active && P.want_reward) {
@@ -286,6 +333,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     STAMP(8);
+    EXIT_AT(7);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
     if (P.want_stats && swarm) {
         // Whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials; two
@@ -401,6 +449,9 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     const int n_a = P.n_a;
     EnvLds<S> L = carve<S>(smem, P, es);
     STAMP(0);
+#ifdef ASM_EXITS
+    const int xat = g_exit_at;
+#endif
     const int n_g = env_ok ? clamp_ng(ng_g[e], P.n_g_max) : 0;
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
@@ -425,6 +476,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     }
     __syncthreads();
     STAMP(1);
+    EXIT_AT(1);
     if constexpr (sizeof(S) == 4) {
         if (P.lat == 2)
             for (int k = i; k < ASM_LAT_NB; k += P.SL) {
@@ -434,15 +486,59 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
             }
     }
 
+    // large swarms: cell list of the old positions for the contact search
+    [[maybe_unused]] BinView BC;
+    [[maybe_unused]] bool use_bins = false;
+    if constexpr (sizeof(S) == 4) {
+        if (!P.periodic && P.SL >= 64 && P.bins) {
+            BC = bins_carve(L.mask, P.bin_c, P.SL);
+            bins_build(P, P.bin_c, BC, i, active, (float)L.px[i], (float)L.py[i]);
+            use_bins = true;
+        }
+    }
+
     double npx = 0, npy = 0, nvx = 0, nvy = 0;
     int contacts = 0;
     if (active) {
         const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
         // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
         double fx = 0.0, fy = 0.0;
-        if (sizeof(S) == 4 && !P.periodic && P.SL >= 64) {                       // large swarm: 32 agents per screen
+        if (sizeof(S) == 4 && !P.periodic && P.SL >= 64) {                       // large swarm
             if constexpr (sizeof(S) == 4) {
                 const float pxf = L.px[i], pyf = L.py[i];
+                // With a cell list: the agents that pass the single-precision screen are gathered from the bins
+                // around, kept as a short list ordered by index (in this agent's row of the word-key area, idle
+                // until the cell pass), then evaluated exactly in ascending k as the reference sums them.
+                bool listed = false;
+                if (use_bins) {
+                    unsigned short *hits = L.wkey + (size_t)i * P.MW;
+                    int nh = 0; bool over = false;
+                    bins_for_each(P, P.bin_c, BC, pxf, pyf, [&](f32x2 c, int k) {
+                        const float rx = c.x - pxf, ry = c.y - pyf;
+                        if (__builtin_fmaf(ry, ry, rx * rx) < P.Tcontact_hi_f && k != i) {
+                            if (nh < P.MW) {
+                                int at = nh++;
+                                for (; at > 0 && (int)hits[at - 1] > k; --at) hits[at] = hits[at - 1];
+                                hits[at] = (unsigned short)k;
+                            } else over = true;
+                        }
+                    });
+                    if (!over) {
+                        listed = true;
+                        for (int t = 0; t < nh; ++t) {
+                            const int k = hits[t];
+                            const double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;
+                            const double s = dx * dx + dy * dy;
+                            if (s < P.T_contact) {
+                                const double d = sqrt(s), gap = fabs(d - P.sizes2);
+                                fx += 1.0 * gap * P.k_ball * (-(dx / d));
+                                fy += 1.0 * gap * P.k_ball * (-(dy / d));
+                                if (k > i) ++contacts;
+                            }
+                        }
+                    }
+                }
+                if (!listed)                                                     // 32 agents per screen
                 for (int j0 = 0; j0 < P.SL; j0 += 32) {
                     unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tcontact_hi_f);
                     if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
@@ -545,6 +641,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     }
     __syncthreads();
     STAMP(3);
+    EXIT_AT(2);
     DevParams Q = P; Q.n_g_e = n_g;
     observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
                stats_g, -1, (sizeof(S) == 4 && P.lat == 2) ? &LV : nullptr);

@@ -137,7 +137,7 @@ def test_lattice_path_large_swarms(torch_cuda, n_a, E):
     from gpu_util import cfg_from_env, teacher_forced_step
     a, b = _pair(E, n_a=n_a, seed=n_a)
     a.reset(); b.reset()
-    assert a.step_schedule() == 32 and b.step_schedule() == 0
+    assert a.step_schedule() & 63 == 32 and b.step_schedule() & 63 == 0     # (+ 64: pair passes through cell lists)
     for t in range(3):
         act = a.random_actions(step=t)
         a.step(act); b.step(act)
