@@ -215,11 +215,14 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
 
     unsigned *mym = L.mask + (size_t)i * P.MW;
     int n_before = 0, n_after = 0, n_occ = 0;
+    unsigned nz = 0;                                                     // words of the sensed list that hold cells (W <= 32)
+    const unsigned occm = in_flag ? 0xFFFFFFFFu : 0u;                    // CPP:155: occupied cells leave the list only inside the shape
     if (active) {
         for (int w = 0; w < P.W; ++w) {
-            unsigned m = mym[w];
+            const unsigned m = mym[w], o = m & L.occ[w] & occm;
             n_before += __popc(m);
-            if (in_flag) { n_occ += __popc(m & L.occ[w]); }              // CPP:155: only when inside the shape
+            n_occ += __popc(o);
+            nz |= (m != o ? 1u : 0u) << (w & 31);
         }
         n_after = n_before - n_occ;
         inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;                 // CPP:139
@@ -267,19 +270,46 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within 2e-4 of 0.05
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
             float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
-            emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
+            auto slot = [&](int k, int cell) {
                 float gx = 0.f, gy = 0.f;
                 if (cell >= 0) {
                     gx = (float)L.gx[cell] - pxf; gy = (float)L.gy[cell] - pyf;          // CPP:285-286
                     if (rew_on) {
-                        const float z = __builtin_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
+                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));   // 1 ulp: inside the 2e-4 margin below
                         const float psi = 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f);   // cos(pi z / d_sen)
                         fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
                     }
                 }
                 ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy;
                 if (sdst) sdst[k] = cell;
-            });
+            };
+            if (P.W <= 32 && ((P.n_obs - 1) & 1)) {
+                // The same emission (CPP:243-296) as one loop over the slots that is uniform across the wave: a lane
+                // walks the non-empty words of its list (nz) bit by bit and once no lane of the wave has a cell left
+                // the slots are zero-filled.  Slot k of a sub-sampled list (n > cap, CPP:246-251) takes bit
+                // round(k (n - 1) / (cap - 1)) = floor((2 k (n - 1) + cap - 1) / (2 (cap - 1))): cap - 1 is odd here, so
+                // the quotient is never half-way and the reference's double arithmetic rounds to the same side.  The
+                // numerator is kept as a running sum; a lane takes one more bit whenever it passes the next multiple
+                // of the denominator (exactly once per slot when the list is not sub-sampled).
+                const int cap = P.n_obs, n_out = n_after < cap ? n_after : cap;
+                const int D = 2 * (cap - 1), inc = n_after > cap ? 2 * (n_after - 1) : D;
+                int acc = cap - 1 - inc, thr = 0;
+                unsigned bits = 0; int wbase = 0, cell = -1;
+                for (int k = 0; k < cap; ++k) {
+                    if (__ballot(k < n_out) == 0) { slot(k, -1); continue; }
+                    acc += inc;
+                    while (k < n_out && acc >= thr) {
+                        thr += D;
+                        if (bits == 0) {
+                            int w = __ffs(nz) - 1; nz &= nz - 1; w = w < 0 ? 0 : w;
+                            bits = mym[w] & ~(L.occ[w] & occm); wbase = w * 32;
+                        }
+                        cell = wbase + __ffs(bits) - 1; bits &= bits - 1;
+                    }
+                    slot(k, k < n_out ? cell : -1);
+                }
+            } else
+            emit_list(it, n_after, P.n_obs, slot);
             if (rew_on && n_after > 0 && fden > 0.f) {
                 const float v0 = fn0 / fden, v1 = fn1 / fden;
                 const float vn = __builtin_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
