@@ -59,7 +59,8 @@ int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // MARL_AMD_FAST_T (tuning / test knob: waves per workgroup of k_step_fast, 0 = generic kernel), read once per process
 // asm_set_step_schedule() overrides it at run time (tests compare the schedules within one process).
-// Bit 4 of the value (+16): the large-swarm pair passes without their cell lists.
+// Bit 4 of the value (+16): the large-swarm pair passes without their cell lists; bit 5 (+32): large swarms as one
+// workgroup per environment even where the step could split them.
 std::atomic<int> g_schedule_override{-1};
 int schedule_setting()
 {
@@ -69,6 +70,7 @@ int schedule_setting()
 }
 int fast_t_setting() { return schedule_setting() & 15; }
 bool cell_lists_off() { return (schedule_setting() & 16) != 0; }
+bool split_off() { return (schedule_setting() & 32) != 0; }
 
 // Launch geometry + thresholds.  state_bytes = sizeof(S).
 int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out);
@@ -95,6 +97,44 @@ int make_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams 
     return 0;
 }
 
+// LDS layout of the generic kernels for P->rows per-agent rows per environment (SL, or fewer for a part workgroup),
+// and the geometry of the large swarms' cell lists, which live in the per-agent mask area (idle until the cell
+// pass): bin counters / starts (one word per bin + 1, + 16 wave totals), then position pairs and 16-bit indices in bin
+// order.  Needs SL, EPB, NGP, W, MW, rows, periodic, half_w, half_h, sizes2, d_sen.  False: does not fit the LDS.
+bool swarm_layout(DevParams *Pp, size_t state_bytes)
+{
+    DevParams &P = *Pp;
+    size_t env_bytes = state_bytes * ((size_t)P.state_rows * P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.rows * P.MW + 2 * (size_t)P.W);
+    if (P.parts <= 1) env_bytes += 2 * (size_t)P.rows * P.MW;            // + 16-bit word keys of the large-swarm cell pass (all-cells path)
+    env_bytes = (env_bytes + 15) / 16 * 16 + 16;                         // + the step's contact counter
+    P.lds_env_bytes = (unsigned)env_bytes;
+    P.lds_block_bytes = (unsigned)(env_bytes * P.EPB);
+    if (P.lds_block_bytes > 160 * 1024) return false;
+    P.bins = 0;
+    if (state_bytes == 4 && !P.periodic && P.EPB == 1 && P.SL >= 256 && !cell_lists_off()) {
+        const size_t region = 4 * (size_t)P.rows * P.MW;
+        auto geom = [&](double radius, int max_reach, asmenv::BinGeom *G) {
+            const double r = radius * 1.001;                        // covers the screens' inflated thresholds and the rounding of the bin coordinates
+            double h = r / max_reach;
+            for (int it = 0; it < 400; ++it, h *= 1.05) {
+                const double nx = std::ceil(2 * P.half_w / h), ny = std::ceil(2 * P.half_h / h);
+                if (!(nx >= 1 && ny >= 1) || nx * ny > 60000) continue;
+                const size_t need = 4 * ((size_t)(nx * ny) + 1 + 16 + 1) + 10 * (size_t)P.SL;
+                if (need > region) continue;
+                G->nbx = (int)nx; G->nby = (int)ny; G->inv_h = (float)(1.0 / h);
+                G->reach = (int)std::ceil(r / h);
+                return true;
+            }
+            return false;
+        };
+        static const int reach_s = [] { const char *v = std::getenv("MARL_AMD_BIN_REACH"); const int r = v ? std::atoi(v) : 3; return r < 1 ? 1 : (r > 8 ? 8 : r); }();
+        if (P.half_w > 0 && P.half_h > 0 && P.sizes2 > 0 && P.d_sen > 0 && geom(P.sizes2, 1, &P.bin_c) && geom(P.d_sen, reach_s, &P.bin_s)) {
+            P.bins = 1; P.bin_x0 = (float)P.half_w; P.bin_y0 = (float)P.half_h;
+        }
+    }
+    return true;
+}
+
 int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out)
 {
     if (!prm) return fail(1, "asm_params is NULL");
@@ -113,12 +153,10 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
     P.NGP = (prm->n_g_max + 31) / 32 * 32;
     P.W = P.NGP / 32;
     P.MW = (P.W | 1) < 9 ? 9 : (P.W | 1);
-    size_t env_bytes = state_bytes * (4 * (size_t)P.SL + 2 * (size_t)P.NGP) + 4 * ((size_t)P.SL * P.MW + 2 * (size_t)P.W) +
-                       2 * (size_t)P.SL * P.MW;                          // + 16-bit word keys of the large-swarm cell pass
-    env_bytes = (env_bytes + 15) / 16 * 16 + 16;                         // + the step's contact counter
-    P.lds_env_bytes = (unsigned)env_bytes;
-    P.lds_block_bytes = (unsigned)(env_bytes * P.EPB);
-    if (P.lds_block_bytes > 160 * 1024)
+    P.rows = P.SL; P.state_rows = 4;
+    P.half_w = prm->half_w; P.half_h = prm->half_h; P.sizes2 = prm->size_a + prm->size_a; P.d_sen = prm->d_sen;
+    P.periodic = prm->is_boundary ? 0 : 1;
+    if (!swarm_layout(&P, state_bytes))
         return fail(1, "n_a = %d with n_g_max = %d needs %u bytes of LDS per workgroup (> 160 KiB)", prm->n_a,
                     prm->n_g_max, P.lds_block_bytes);
     P.topo = 6; P.n_obs = prm->num_obs_grid_max; P.n_occ = prm->num_occupied_grid_max;
@@ -166,31 +204,6 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
         }
     }
-    // Large swarms (one environment per workgroup, walls, fp32 state): cell lists for the two pair passes.  They live in
-    // the per-agent mask area of the environment's LDS block, which is idle until the cell pass: bin counters / starts
-    // (one word per bin + 1, + 16 wave totals), then position pairs and 16-bit indices in bin order.
-    P.bins = 0;
-    if (state_bytes == 4 && !P.periodic && P.EPB == 1 && P.SL >= 256 && !cell_lists_off()) {
-        const size_t region = 4 * (size_t)P.SL * P.MW;
-        auto geom = [&](double radius, int max_reach, asmenv::BinGeom *G) {
-            const double r = radius * 1.001;                        // covers the screens' inflated thresholds and the rounding of the bin coordinates
-            double h = r / max_reach;
-            for (int it = 0; it < 400; ++it, h *= 1.05) {
-                const double nx = std::ceil(2 * P.half_w / h), ny = std::ceil(2 * P.half_h / h);
-                if (!(nx >= 1 && ny >= 1) || nx * ny > 60000) continue;
-                const size_t need = 4 * ((size_t)(nx * ny) + 1 + 16 + 1) + 10 * (size_t)P.SL;
-                if (need > region) continue;
-                G->nbx = (int)nx; G->nby = (int)ny; G->inv_h = (float)(1.0 / h);
-                G->reach = (int)std::ceil(r / h);
-                return true;
-            }
-            return false;
-        };
-        static const int reach_s = [] { const char *v = std::getenv("MARL_AMD_BIN_REACH"); const int r = v ? std::atoi(v) : 3; return r < 1 ? 1 : (r > 8 ? 8 : r); }();
-        if (P.half_w > 0 && P.half_h > 0 && P.sizes2 > 0 && P.d_sen > 0 && geom(P.sizes2, 1, &P.bin_c) && geom(P.d_sen, reach_s, &P.bin_s)) {
-            P.bins = 1; P.bin_x0 = (float)P.half_w; P.bin_y0 = (float)P.half_h;
-        }
-    }
     *out = P;
     return 0;
 }
@@ -230,6 +243,22 @@ bool lattice_usable_swarm(const asm_lattice *lat, const asm_params *prm, DevPara
     if (P->lds_block_bytes + extra > 160 * 1024) return false;
     P->lds_env_bytes += extra; P->lds_block_bytes += extra;
     P->lat = 2; P->lat_KO = Q.lat_KO; P->lat_cb = Q.lat_cb;
+    return true;
+}
+
+// A large swarm's step as three launches, the observation split over SL / 256 workgroups per environment (see
+// launch_step_split): on the lattice path with cell lists only.  Fills the part workgroups' parameters.
+bool split_usable(DevParams *P, DevParams *part)
+{
+    if (P->lat != 2 || !P->bins || P->SL < 512 || P->W > 32 || split_off()) return false;
+    DevParams Q = *P;
+    Q.rows = 256; Q.parts = P->SL / 256; Q.state_rows = 2;
+    if (!swarm_layout(&Q, sizeof(float)) || !Q.bins) return false;
+    const unsigned extra = 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS + 2 * ASM_LAT_NB + 8 * ASM_LAT_NB;
+    Q.lds_env_bytes += extra; Q.lds_block_bytes += extra;
+    P->parts = Q.parts;
+    Q.state_rows = 2;
+    *part = Q;
     return true;
 }
 
@@ -414,11 +443,17 @@ int asm_batch_step_f32(const asm_params *prm, int E, float *p, float *dp, const 
     asmenv::LatArgs LA{};
     if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
     else lattice_usable_swarm(lattice, prm, &P, &LA);
-    int rc = P.fast_T
-        ? asmenv::launch_step_fast(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
-                                   a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream)
-        : asmenv::launch_step<float>(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
-                                     reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
+    DevParams part;
+    int rc;
+    if (P.fast_T)
+        rc = asmenv::launch_step_fast(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs, reward,
+                                      a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
+    else if (split_usable(&P, &part))
+        rc = asmenv::launch_step_split(P, part, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+                                       reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
+    else
+        rc = asmenv::launch_step<float>(P, LA, p, dp, act, grid, n_g, l_cell, neighbor_index, in_flags, nearest_cell, obs,
+                                        reward, a_prior, sensed_index, occupied_index, stats, (hipStream_t)stream);
     return rc ? hip_fail(rc, "asm_batch_step_f32") : 0;
 }
 
@@ -519,7 +554,9 @@ int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lat
     asmenv::LatArgs LA{};
     if (P.fast_T) lattice_usable(lattice, prm, &P, &LA);
     else lattice_usable_swarm(lattice, prm, &P, &LA);
-    return P.fast_T + 16 * P.lat + 64 * P.bins;
+    DevParams part;
+    const int split = !P.fast_T && split_usable(&P, &part) ? 1 : 0;
+    return P.fast_T + 16 * P.lat + 64 * P.bins + 128 * split;
 }
 
 #ifdef ASM_DIAG

@@ -33,12 +33,16 @@ struct DevParams {
     int observe_only;               // k_step_fast: no dynamics, the state is observed as it is (reset, observe)
     int state_only;                 // k_reset: draw the state and the grid only; the observation comes from another launch
     int n_g_e;                      // set per environment inside the kernels
+    int part;                       // set per workgroup inside the part kernel: which part of the environment it observes
     int block, grid;
     unsigned lds_env_bytes, lds_block_bytes;
     int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
     unsigned fast_lds_bytes;
     int lat, lat_KO;                // lattice path: 0 off, 1 k_step_fast, 2 k_step (large swarms); lattice rows |k| <= lat_KO can hold an occupied cell
     float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)
+    int state_rows;                 // state arrays of SL entries kept in LDS: 4 (px, py, vx, vy), or 2 for a part workgroup (velocities stay in global memory)
+    int rows;                       // per-agent LDS rows (sensed masks, word keys) of one workgroup: SL, or SL / parts for a part workgroup
+    int parts;                      // large swarms: the observation of an environment is split over this many workgroups (0, 1: not split)
     int bins;                       // large swarms: the pair passes (contacts, k nearest neighbours) go through cell lists
     BinGeom bin_c, bin_s;           // ... sized for the contact distance and for the sensing radius
     float bin_x0, bin_y0;           // half_w, half_h in single precision
@@ -76,6 +80,11 @@ int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t en
                  S *obs, int *sensed, int *occupied, double *xform, hipStream_t st);
 int launch_check_lattice(int E, int n_g_max, const float *grid, const int *n_g, const LatArgs &lat, double tol, int *n_bad,
                          hipStream_t st);
+// The large-swarm step as three launches: dynamics (one workgroup per environment), observation + reward (P.parts
+// workgroups per environment), statistics.  Q: the parameters of a part workgroup (rows, LDS size).
+int launch_step_split(const DevParams &P, const DevParams &Q, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid,
+                      const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew,
+                      float *prior, int *sensed, int *occupied, double *stats, hipStream_t st);
 int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid, const int *n_g,
                      const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew, float *prior,
                      int *sensed, int *occupied, double *stats, hipStream_t st);

@@ -142,6 +142,22 @@ int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float
     return 0;
 }
 
+int launch_step_split(const DevParams &P, const DevParams &Q, const LatArgs &lat, float *p, float *dp, const float *act, const float *grid,
+                      const int *n_g, const double *l_cell, int *nbr, int *inflags, int *nearest, float *obs, float *rew,
+                      float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
+{
+    if (int rc = launch_step<float>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st)) return rc;
+    if (int rc = set_lds(k_observe_part, Q.lds_block_bytes)) return rc;
+    hipLaunchKernelGGL(k_observe_part, dim3((unsigned)P.E * Q.parts), dim3(Q.rows), Q.lds_block_bytes, st, Q, lat, p, dp, grid, n_g, l_cell,
+                       nbr, inflags, nearest, obs, rew, sensed, occupied, stats);
+    LAUNCH_CHECK();
+    if (stats) {
+        hipLaunchKernelGGL(k_swarm_stats, dim3((unsigned)P.E), dim3(P.SL), 0, st, P, p, grid, nbr, inflags, nearest, rew, stats);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 template <typename S>
 int launch_reset(const DevParams &P, uint64_t seed, uint32_t episode, int64_t env0, int n_shapes,
                  const double *shape_grids, const int *shape_off, const int *shape_ng, const double *shape_lcell,

@@ -56,9 +56,9 @@ __device__ __forceinline__ EnvLds<S> carve(unsigned char *base, const DevParams 
     EnvLds<S> L;
     S *f = reinterpret_cast<S *>(b);
     L.px = f; L.py = f + P.SL; L.vx = f + 2 * P.SL; L.vy = f + 3 * P.SL;
-    L.gx = f + 4 * P.SL; L.gy = L.gx + P.NGP;
+    L.gx = f + P.state_rows * P.SL; L.gy = L.gx + P.NGP;
     unsigned *u = reinterpret_cast<unsigned *>(L.gy + P.NGP);
-    L.mask = u; L.occ = u + (size_t)P.SL * P.MW; L.cov = L.occ + P.W;
+    L.mask = u; L.occ = u + (size_t)P.rows * P.MW; L.cov = L.occ + P.W;
     L.wkey = reinterpret_cast<unsigned short *>(L.cov + P.W);
     L.cnt = reinterpret_cast<int *>(b + P.lds_env_bytes - 16);          // the last 16 bytes of the environment's block
     L.lat = b + P.lds_env_bytes - 16 - ASM_LAT_LDS_BYTES;               // only there when P.lat == 2
@@ -204,35 +204,49 @@ __device__ __forceinline__ int bin_coord(float x, float x0, float inv_h, int nb)
     return (int)v;
 }
 
-// Builds the list for the positions (x, y) of the workgroup's agents.  Reached by every thread; five barriers, the
-// first of which also orders this build after whatever used the region before.
-__device__ __forceinline__ void bins_build(const DevParams &P, const BinGeom &G, const BinView &B, int i, bool active, float x, float y)
+// Builds the list of the environment's agents 0 .. n - 1 (positions X, Y in LDS) with the nthr threads t = 0 .. nthr - 1
+// of the workgroup (nthr a multiple of 64, at least SL / 4: up to four agents per thread).  Reached by every thread;
+// five barriers, the first of which also orders this build after whatever used the region before.
+__device__ __forceinline__ void bins_build(const DevParams &P, const BinGeom &G, const BinView &B, int t, int nthr, int n,
+                                           const float *X, const float *Y)
 {
-    const int SL = P.SL, nb1 = G.nbx * G.nby + 1;
+    const int nb1 = G.nbx * G.nby + 1;
     __syncthreads();
-    for (int k = i; k < nb1 + 16; k += SL) B.start[k] = 0;
+    for (int k = t; k < nb1 + 16; k += nthr) B.start[k] = 0;
     __syncthreads();
-    int b = 0; unsigned rank = 0;
-    if (active) {
-        b = bin_coord(y, P.bin_y0, G.inv_h, G.nby) * G.nbx + bin_coord(x, P.bin_x0, G.inv_h, G.nbx);
-        rank = atomicAdd(&B.start[b], 1u);
+    int b[4]; unsigned rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int a = t + u * nthr;
+        b[u] = -1; rank[u] = 0;
+        if (a < n) {
+            b[u] = bin_coord(Y[a], P.bin_y0, G.inv_h, G.nby) * G.nbx + bin_coord(X[a], P.bin_x0, G.inv_h, G.nbx);
+            rank[u] = atomicAdd(&B.start[b[u]], 1u);
+        }
     }
     __syncthreads();
-    // exclusive prefix sum in place: thread i owns C consecutive counters (C odd: conflict-free strides)
-    const int C = ((nb1 + SL - 1) / SL) | 1, k0 = i * C;
+    // exclusive prefix sum in place: thread t owns C consecutive counters (C odd: conflict-free strides)
+    const int C = ((nb1 + nthr - 1) / nthr) | 1, k0 = t * C;
     unsigned sum = 0;
     for (int k = 0; k < C; ++k) if (k0 + k < nb1) sum += B.start[k0 + k];
     unsigned incl = sum;
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) { const unsigned t = __shfl_up(incl, m, 64); if ((i & 63) >= m) incl += t; }
+    for (int m = 1; m < 64; m <<= 1) { const unsigned v = __shfl_up(incl, m, 64); if ((t & 63) >= m) incl += v; }
     unsigned *wtot = B.start + nb1;
-    if ((i & 63) == 63) wtot[i >> 6] = incl;
+    if ((t & 63) == 63) wtot[t >> 6] = incl;
     __syncthreads();
     unsigned run = incl - sum;
-    for (int w = 0; w < (i >> 6); ++w) run += wtot[w];
+    for (int w = 0; w < (t >> 6); ++w) run += wtot[w];
     for (int k = 0; k < C; ++k) if (k0 + k < nb1) { const unsigned c = B.start[k0 + k]; B.start[k0 + k] = run; run += c; }
     __syncthreads();
-    if (active) { const unsigned at = B.start[b] + rank; const f32x2 q = {x, y}; B.pos[at] = q; B.idx[at] = (unsigned short)i; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (b[u] >= 0) {
+            const int a = t + u * nthr;
+            const unsigned at = B.start[b[u]] + rank[u];
+            const f32x2 q = {X[a], Y[a]};
+            B.pos[at] = q; B.idx[at] = (unsigned short)a;
+        }
     __syncthreads();
 }
 

@@ -3,16 +3,61 @@
 // Part of the single translation unit asm_kernels.hip (included there, inside namespace asmenv, after the
 // diagnostic macros); not a stand-alone header.
 
+// Per-environment step statistics of a large swarm (TRAIN:128-135; WRAP:48-165), one environment per workgroup of SL
+// threads: wave shuffles, then the wave partials through `part` ([SL / 64][8] doubles of LDS); two barriers.  The
+// variance of the nearest-neighbour distances (WRAP:96) is taken as E[m^2] - mean^2 from one pass (relative error
+// ~1e-13 at these magnitudes).  cov (nullable): the environment's coverage bitmap, counted into st[2]; contacts < 0:
+// st[4] is left alone.
+__device__ __forceinline__ void swarm_stats(const DevParams &P, double *part, int i, bool active, int e, double reward,
+                                            double dmin, bool in_flag, double nn_min, const unsigned *cov, double contacts,
+                                            double *stats_g)
+{
+    const int n_a = P.n_a;
+    const int wave = i >> 6, nw = P.SL >> 6;
+    const double mloc = active ? sqrt(nn_min) : 0.0;
+    double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0, mloc,
+                   active ? mloc : __builtin_inf(), active ? mloc : -__builtin_inf(), mloc * mloc};
+    if (cov && wave == 0 && (i & 63) < P.W) v[2] += 65536.0 * __popc(cov[i & 63]);   // covered cells ride along (W <= 32 words)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
+        v[3] += __shfl_xor(v[3], m, 64); v[6] += __shfl_xor(v[6], m, 64);
+        v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
+    }
+    if ((i & 63) == 0) for (int q = 0; q < 7; ++q) part[wave * 8 + q] = v[q];
+    __syncthreads();
+    if (i == 0 && e < P.E) {
+        double rs = 0, ds = 0, ic = 0, ms = 0, sq = 0, lo = __builtin_inf(), hi = -__builtin_inf();
+        for (int w = 0; w < nw; ++w) {
+            rs += part[w * 8]; ds += part[w * 8 + 1]; ic += part[w * 8 + 2]; ms += part[w * 8 + 3]; sq += part[w * 8 + 6];
+            lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
+        }
+        const double covered = floor(ic / 65536.0), inn = ic - 65536.0 * covered;    // both are small integers
+        const double mean = ms / n_a, var = sq / n_a - mean * mean;
+        double *st = stats_g + (size_t)e * 8;
+        st[0] += rs; st[1] += rs;                                        // rewards are 0 or 1
+        if (cov) st[2] += P.n_g_e > 0 ? covered / P.n_g_e : 0.0;
+        st[3] += (var - lo) / (hi - lo);                                 // WRAP:98-99
+        if (contacts >= 0) st[4] += contacts;
+        st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Observation + reward of environment e for agent i on the state held in LDS.
 // CPP:23-356 (observation), CPP:359-631 (reward).  Must be reached by every thread.
+// The environment's nthr threads are numbered row = 0 .. nthr - 1; row is also the thread's per-agent LDS row (sensed
+// mask, word keys).  One workgroup per environment: row = i, nthr = SL.  A part workgroup (P.parts > 1) observes the
+// agents i = part * nthr + row on the state of ALL agents: it lists every agent in its bins, and marks the
+// occupancy / coverage bits of the other parts' agents too (lattice path only), because the occupied-cell filter
+// (CPP:155-212) needs the whole environment's bitmap.
 //
 // S = float takes single-precision screening paths wherever a decision is certain in
 // fp32 and falls back to the exact double evaluation otherwise (cell_pass_fast above;
 // the neighbour and reward screens below follow the same rule), so its decisions are
 // those of the all-double code; S = double is the all-double code.
 template <typename S>
-__device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, double l_cell,
+__device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, int row, int nthr, double l_cell,
                         const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
                         int *sensed_g, int *occup_g, double *stats_g, int contact_pairs, const LatView *LV = nullptr)
 {
@@ -32,7 +77,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     if constexpr (F32) {
         if (swarm && P.bins) {
             BVs = bins_carve(L.mask, P.bin_s, P.SL);
-            bins_build(P, P.bin_s, BVs, i, active, (float)L.px[i], (float)L.py[i]);
+            bins_build(P, P.bin_s, BVs, row, nthr, P.n_a, reinterpret_cast<const float *>(L.px), reinterpret_cast<const float *>(L.py));
             BV = &BVs;
         }
     }
@@ -55,23 +100,59 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             if constexpr (F32) {
                 const float pxf = L.px[i], pyf = L.py[i];
                 // Candidates (fp32 screen) go through a min/max insertion chain on single-precision keys (s32 with
-                // the low 10 bits replaced by the index) that keeps the 7 smallest.  The list is read off the keys
-                // when every neighbouring pair differs by at least two units of 1024 ulps and every listed key lies
-                // two units below T_sen; otherwise this agent redoes its list with exact double insertion.
-                // The candidates come from the cell list when there is one (any order: the keys are distinct),
-                // else from screens of 32 agents at a time.
-                unsigned K[7];
+                // the low 10 bits replaced by the index) that keeps the 8 smallest.  The list is read off the keys
+                // when every neighbouring pair of the first seven differs by at least two units of 1024 ulps (the
+                // double-precision order is then the keys' order) and every listed key lies two units below T_sen.
+                // Otherwise the first seven are ordered and filtered exactly, in double: that settles the list as
+                // long as the eighth key lies two units above the sixth (nobody beyond the seven can be among the
+                // six nearest); if not even that holds, the agent redoes its list with exact insertion of every
+                // candidate.  The candidates come from the cell list when there is one (any order: the keys are
+                // distinct), else from screens of 32 agents at a time.
+                unsigned K[8];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) K[q] = 0xFFFFFFFFu;
-                if (BV)
-                    bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
-                        const float rx = c.x - pxf, ry = c.y - pyf, s32 = __builtin_fmaf(ry, ry, rx * rx);
-                        if (s32 < P.Tsen_hi_f && j != i) {                              // self removed CPP:677-681
-                            unsigned x = (__float_as_uint(s32) & ~1023u) | (unsigned)j;
+                for (int q = 0; q < 8; ++q) K[q] = 0xFFFFFFFFu;
+                auto insert_exact = [&](int j, double s) {                      // (s, j) ascending: ties keep the lower index
+                    double ks = s; int kj = j; bool placed = false;
 #pragma unroll
-                            for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                    for (int q = 0; q < 6; ++q)
+                        if (placed || ks < s6[q] || (ks == s6[q] && kj < j6[q])) {
+                            const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true;
                         }
-                    });
+                };
+                if (BV) {
+                    // Rows of bins nearest first; once eight candidates are held, only keys below the eighth can still
+                    // enter the list, so the screen's threshold follows it down and the rows (and the bins of a row)
+                    // that lie beyond it are skipped: a row m >= 2 bin rows away holds nobody closer than (m - 1) bin
+                    // sides, a bin k >= 1 columns away nobody closer than k - 1 (0.1 % slack for the rounding of the
+                    // bin coordinates).
+                    const BinGeom &G = P.bin_s;
+                    const int bx = bin_coord(pxf, P.bin_x0, G.inv_h, G.nbx), by = bin_coord(pyf, P.bin_y0, G.inv_h, G.nby);
+                    const float hs = 0.999f / G.inv_h;
+                    const unsigned tsen_bits = __float_as_uint(P.Tsen_hi_f);
+                    float thr = P.Tsen_hi_f;
+                    for (int t = 0; t <= 2 * G.reach; ++t) {
+                        const int m = (t + 1) >> 1, r = by + ((t & 1) ? -m : m);
+                        const float dr = m > 1 ? (float)(m - 1) * hs : 0.f, rem = thr - dr * dr;
+                        if (r < 0 || r >= G.nby || !(rem > 0.f)) continue;
+                        int kx = (int)(__builtin_amdgcn_sqrtf(rem) * G.inv_h * 1.001f) + 1;
+                        kx = kx < G.reach ? kx : G.reach;
+                        const int xa = bx - kx > 0 ? bx - kx : 0, xb = bx + kx < G.nbx - 1 ? bx + kx : G.nbx - 1;
+                        unsigned u = BV->start[r * G.nbx + xa];
+                        const unsigned hi = BV->start[r * G.nbx + xb + 1];
+                        for (; u < hi; ++u) {
+                            const f32x2 c = BV->pos[u];
+                            const int j = BV->idx[u];
+                            const float rx = c.x - pxf, ry = c.y - pyf, s32 = __builtin_fmaf(ry, ry, rx * rx);
+                            if (s32 < thr && j != i) {                                  // self removed CPP:677-681
+                                unsigned x = (__float_as_uint(s32) & ~1023u) | (unsigned)j;
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                                const unsigned tb = K[7] | 1023u;                       // every key of the eighth's 1024-ulp bucket still passes
+                                thr = __uint_as_float(tb < tsen_bits ? tb + 1u : tsen_bits);
+                            }
+                        }
+                    }
+                }
                 else
                 for (int j0 = 0; j0 < P.SL; j0 += 32) {
                     unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
@@ -81,19 +162,32 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                         const float rx = L.px[j] - pxf, ry = L.py[j] - pyf;
                         unsigned x = (__float_as_uint(__builtin_fmaf(ry, ry, rx * rx)) & ~1023u) | (unsigned)j;
 #pragma unroll
-                        for (int q = 0; q < 7; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
+                        for (int q = 0; q < 8; ++q) { const unsigned lo = K[q] < x ? K[q] : x; x = K[q] < x ? x : K[q]; K[q] = lo; }
                     }
                 }
                 const unsigned tlo = (__float_as_uint(P.Tsen_f) >> 10) - 2u;
-                bool redo = false;
+                bool amb = false;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
                     const bool there = K[q] != 0xFFFFFFFFu;
                     const unsigned u = K[q] >> 10;
-                    redo |= there && (u >= tlo || (K[q + 1] >> 10) - u < 2u);
+                    amb |= there && (u >= tlo || (K[q + 1] >> 10) - u < 2u);
                     j6[q] = there ? (int)(K[q] & 1023u) : -1;
                 }
-                if (redo && BV) {                                               // rare; candidates in any order: (s, j) decides
+                const bool redo = amb && K[5] != 0xFFFFFFFFu && (K[7] >> 10) - (K[5] >> 10) < 2u;
+                if (amb && !redo) {                                             // the first seven, exactly
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) j6[q] = -1;
+#pragma unroll
+                    for (int q = 0; q < 7; ++q)
+                        if (K[q] != 0xFFFFFFFFu) {
+                            const int j = (int)(K[q] & 1023u);
+                            const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                            const double s = dx * dx + dy * dy;                 // CPP:641
+                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
+                        }
+                }
+                if (redo && BV) {                                               // very rare
 #pragma unroll
                     for (int q = 0; q < 6; ++q) j6[q] = -1;
                     bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
@@ -101,14 +195,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                         if (__builtin_fmaf(ry, ry, rx * rx) < P.Tsen_hi_f && j != i) {
                             const double dx = (double)c.x - px, dy = (double)c.y - py;
                             const double s = dx * dx + dy * dy;                 // CPP:641
-                            if (s < P.T_sen) {                                  // CPP:663
-                                double ks = s; int kj = j; bool placed = false;
-#pragma unroll
-                                for (int q = 0; q < 6; ++q)
-                                    if (placed || ks < s6[q] || (ks == s6[q] && kj < j6[q])) {
-                                        const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true;
-                                    }
-                            }
+                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
                         }
                     });
                 } else if (redo) {
@@ -117,11 +204,11 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                     for (int j0 = 0; j0 < P.SL; j0 += 32) {
                         unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
                         if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
-                        while (m) {                                             // ascending j: ties keep the lower index
+                        while (m) {
                             const int j = j0 + __ffs(m) - 1; m &= m - 1;
                             const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
                             const double s = dx * dx + dy * dy;                 // CPP:641
-                            if (s < P.T_sen) consider(j, s);                    // CPP:663
+                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
                         }
                     }
                 }
@@ -129,7 +216,34 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                     double s0 = 0.0;
                     if (j6[0] >= 0) { const double dx = (double)L.px[j6[0]] - px, dy = (double)L.py[j6[0]] - py; s0 = dx * dx + dy * dy; }
                     if (s0 > 0.0) nn_min = s0;
-                    else
+                    else if (BV) {
+                        // nobody in sensing range (or a coincident agent): rings of bins outwards, until the nearest
+                        // found so far is closer than anything a further ring can hold (ring m lies more than m - 1
+                        // bin sides away)
+                        const BinGeom &G = P.bin_s;
+                        const int bx = bin_coord(pxf, P.bin_x0, G.inv_h, G.nbx), by = bin_coord(pyf, P.bin_y0, G.inv_h, G.nby);
+                        const double hd = 0.999 / (double)G.inv_h;
+                        const int mmax = G.nbx > G.nby ? G.nbx : G.nby;
+                        auto scan = [&](int r, int xa, int xb) {
+                            for (unsigned u = BV->start[r * G.nbx + xa], hi = BV->start[r * G.nbx + xb + 1]; u < hi; ++u) {
+                                const f32x2 c = BV->pos[u];
+                                const double rx = (double)c.x - px, ry = (double)c.y - py, su = rx * rx + ry * ry;
+                                if (su != 0 && su < nn_min) nn_min = su;
+                            }
+                        };
+                        for (int m = 0; m <= mmax; ++m) {
+                            if (m >= 2 && nn_min <= ((m - 1) * hd) * ((m - 1) * hd)) break;
+                            const int xa = bx - m > 0 ? bx - m : 0, xb = bx + m < G.nbx - 1 ? bx + m : G.nbx - 1;
+                            for (int r = by - m; r <= by + m; ++r) {
+                                if (r < 0 || r >= G.nby) continue;
+                                if (r == by - m || r == by + m) scan(r, xa, xb);
+                                else {
+                                    if (bx - m >= 0) scan(r, bx - m, bx - m);
+                                    if (bx + m < G.nbx) scan(r, bx + m, bx + m);
+                                }
+                            }
+                        }
+                    } else
                         for (int j = 0; j < n_a; ++j) {
                             const double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py, su = rx * rx + ry * ry;
                             if (su != 0 && su < nn_min) nn_min = su;
@@ -187,7 +301,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     STAMP(4);
     EXIT_AT(3);
     // ---- nearest target cell, sensed mask, occupancy bitmaps: CPP:863-913, 145-212 ----
-    for (int w = i; w < 2 * P.W; w += P.SL) L.occ[w] = 0;               // occ and cov are adjacent
+    for (int w = row; w < 2 * P.W; w += nthr) L.occ[w] = 0;             // occ and cov are adjacent
     __syncthreads();
     double smin = 0.0; int imin = 0;
     if (active) {
@@ -195,17 +309,22 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if constexpr (F32) {
             if (swarm) {
                 if (LV)                                                  // the shapes' lattice description is at hand
-                    imin = lat_cell_pass_lane(P, *LV, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW, L.occ, L.cov);
+                    imin = lat_cell_pass_lane(P, *LV, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)row * P.MW, L.occ, L.cov);
                 else
-                    imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)i * P.MW,
-                                           L.wkey + (size_t)i * P.MW, L.occ, L.cov);
+                    imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)row * P.MW,
+                                           L.wkey + (size_t)row * P.MW, L.occ, L.cov);
                 done = true;
             } else
                 done = cell_pass_fast(P, (float)L.px[i], (float)L.py[i], reinterpret_cast<const float *>(L.gx),
-                                      reinterpret_cast<const float *>(L.gy), i, L.mask, L.occ, L.cov, imin);
+                                      reinterpret_cast<const float *>(L.gy), row, L.mask, L.occ, L.cov, imin);
             if (done) { const double rx = (double)L.gx[imin] - px, ry = (double)L.gy[imin] - py; smin = rx * rx + ry * ry; }
         }
-        if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, i, L.mask, L.occ, L.cov, smin, imin);
+        if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, row, L.mask, L.occ, L.cov, smin, imin);
+    }
+    if constexpr (F32) {
+        if (P.parts > 1 && LV)                                           // the other parts' agents: their occupancy / coverage bits
+            for (int a = row; a < n_a; a += nthr)
+                if (a != i) lat_occupancy_lane(P, *LV, L.px[a], L.py[a], L.gx, L.gy, L.occ, L.cov);
     }
     STAMP(5);
     EXIT_AT(4);
@@ -213,7 +332,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
     __syncthreads();
 
-    unsigned *mym = L.mask + (size_t)i * P.MW;
+    unsigned *mym = L.mask + (size_t)row * P.MW;
     int n_before = 0, n_after = 0, n_occ = 0;
     unsigned nz = 0;                                                     // words of the sensed list that hold cells (W <= 32)
     const unsigned occm = in_flag ? 0xFFFFFFFFu : 0u;                    // CPP:155: occupied cells leave the list only inside the shape
@@ -267,7 +386,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         const bool rew_on = in_flag && P.want_reward;
         if constexpr (F32) {
             // values: fl32(cell - p) is the correctly rounded difference either way; reward
-            // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within 2e-4 of 0.05
+            // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within the error bound of 0.05
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
             float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
             auto slot = [&](int k, int cell) {
@@ -275,7 +394,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 if (cell >= 0) {
                     gx = (float)L.gx[cell] - pxf; gy = (float)L.gy[cell] - pyf;          // CPP:285-286
                     if (rew_on) {
-                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));   // 1 ulp: inside the 2e-4 margin below
+                        const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(gy, gy, gx * gx));
                         const float psi = 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f);   // cos(pi z / d_sen)
                         fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
                     }
@@ -311,9 +430,16 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             } else
             emit_list(it, n_after, P.n_obs, slot);
             if (rew_on && n_after > 0 && fden > 0.f) {
-                const float v0 = fn0 / fden, v1 = fn1 / fden;
-                const float vn = __builtin_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
-                if (__builtin_fabsf(vn - 0.05f) > 2e-4f) { uniform = vn < 0.05f; uniform_known = true; }
+                // Single-precision screen.  The weights psi carry an absolute error below 1e-6 (argument rounding
+                // 2*pi*1.5e-7, v_cos_f32 below 5e-7, halved, plus one rounding), every term and every accumulation
+                // step a relative rounding of 6e-8, so with n terms and |g| < d_sen
+                // |v32 - v| < 0.64 n (1e-6 / den + 6e-8) + 1e-7 for the norm v of the mean offset; doubled here.
+                const float rden = 1.0f / fden;
+                const float v0 = fn0 * rden, v1 = fn1 * rden;
+                const float vn = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                const int n_terms = n_after < P.n_obs ? n_after : P.n_obs;
+                const float margin = 1.28f * (float)n_terms * __builtin_fmaf(1e-6f, rden, 6e-8f) + 2e-7f;
+                if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; uniform_known = true; }
             }
             if (rew_on && n_after > 0 && !uniform_known) {               // borderline: the exact sums
                 BitIter it2; it2.init(mym, P.W, L.occ, true);
@@ -365,38 +491,18 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     STAMP(8);
     EXIT_AT(7);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
-    if (P.want_stats && swarm) {
-        // Whole-workgroup reductions (one environment per workgroup here): wave shuffles, then the wave partials; two
-        // barriers in all (16-wave barriers are what this kernel waits on most).  The variance of the nearest-neighbour
-        // distances (WRAP:96) is taken as E[m^2] - mean^2 from one pass (relative error ~1e-13 at these magnitudes).
+    if (P.want_stats && P.parts > 1) {
+        // an environment split over several workgroups: the statistics come from a launch of their own (k_swarm_stats);
+        // the covered cells (WRAP:48-72) are counted here, by the first part, from the whole environment's bitmap
+        if (P.part == 0 && row == 0 && e < P.E) {
+            int covered = 0;
+            for (int w = 0; w < P.W; ++w) covered += __popc(L.cov[w]);
+            stats_g[(size_t)e * 8 + 2] += P.n_g_e > 0 ? (double)covered / P.n_g_e : 0.0;
+        }
+    } else if (P.want_stats && swarm) {
         __syncthreads();                                                 // masks no longer needed
-        const int wave = i >> 6, nw = P.SL >> 6;
-        double *part = reinterpret_cast<double *>(L.mask);               // [nw][8]
-        const double mloc = active ? sqrt(nn_min) : 0.0;
-        double v[7] = {active ? reward : 0.0, active ? dmin : 0.0, active && in_flag ? 1.0 : 0.0, mloc,
-                       active ? mloc : __builtin_inf(), active ? mloc : -__builtin_inf(), mloc * mloc};
-        if (wave == 0 && (i & 63) < P.W) v[2] += 65536.0 * __popc(L.cov[i & 63]);   // covered cells ride along (W <= 32 words)
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64); v[2] += __shfl_xor(v[2], m, 64);
-            v[3] += __shfl_xor(v[3], m, 64); v[6] += __shfl_xor(v[6], m, 64);
-            v[4] = fmin(v[4], __shfl_xor(v[4], m, 64)); v[5] = fmax(v[5], __shfl_xor(v[5], m, 64));
-        }
-        if ((i & 63) == 0) for (int q = 0; q < 7; ++q) part[wave * 8 + q] = v[q];
-        __syncthreads();
-        if (i == 0 && e < P.E) {
-            double rs = 0, ds = 0, ic = 0, ms = 0, sq = 0, lo = __builtin_inf(), hi = -__builtin_inf();
-            for (int w = 0; w < nw; ++w) {
-                rs += part[w * 8]; ds += part[w * 8 + 1]; ic += part[w * 8 + 2]; ms += part[w * 8 + 3]; sq += part[w * 8 + 6];
-                lo = fmin(lo, part[w * 8 + 4]); hi = fmax(hi, part[w * 8 + 5]);
-            }
-            const double covered = floor(ic / 65536.0), inn = ic - 65536.0 * covered;    // both are small integers
-            const double mean = ms / n_a, var = sq / n_a - mean * mean;
-            double *st = stats_g + (size_t)e * 8;
-            st[0] += rs; st[1] += rs; st[2] += P.n_g_e > 0 ? covered / P.n_g_e : 0.0;   // rewards are 0 or 1
-            st[3] += (var - lo) / (hi - lo);                                 // WRAP:98-99
-            st[4] += (double)(contact_pairs < 0 ? *L.cnt : contact_pairs); st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
-        }
+        swarm_stats(P, reinterpret_cast<double *>(L.mask), i, active, e, reward, dmin, in_flag, nn_min, L.cov,
+                    (double)(contact_pairs < 0 ? *L.cnt : contact_pairs), stats_g);
     } else if (P.want_stats) {
         __syncthreads();                                                 // masks no longer needed
         double *scr = reinterpret_cast<double *>(L.mask);                // 4 doubles per agent (MW >= 8 words)
@@ -463,7 +569,7 @@ __global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *hea
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     __syncthreads();
     DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0;
-    observe<S>(Q, L, active, e, i, l_cell, heading_g, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+    observe<S>(Q, L, active, e, i, i, P.SL, l_cell, heading_g, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
                nullptr, 0);
 }
 
@@ -522,7 +628,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     if constexpr (sizeof(S) == 4) {
         if (!P.periodic && P.SL >= 64 && P.bins) {
             BC = bins_carve(L.mask, P.bin_c, P.SL);
-            bins_build(P, P.bin_c, BC, i, active, (float)L.px[i], (float)L.py[i]);
+            bins_build(P, P.bin_c, BC, i, P.SL, P.n_a, reinterpret_cast<const float *>(L.px), reinterpret_cast<const float *>(L.py));
             use_bins = true;
         }
     }
@@ -672,9 +778,94 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     __syncthreads();
     STAMP(3);
     EXIT_AT(2);
+    if (P.parts > 1) {                                               // the observation of the new state is the part launch's
+        if (P.want_stats && i == 0 && env_ok) stats_g[(size_t)e * 8 + 4] += (double)*L.cnt;
+        return;
+    }
     DevParams Q = P; Q.n_g_e = n_g;
-    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+    observe<S>(Q, L, active, e, i, i, P.SL, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
                stats_g, -1, (sizeof(S) == 4 && P.lat == 2) ? &LV : nullptr);
+}
+
+// Observation + reward of the state in p_g / dp_g for large swarms on the lattice path, an environment split over
+// P.parts workgroups of SL / P.parts threads (blockIdx = environment * parts + part).  Each part holds the whole
+// environment's state, grid and lattice tables in LDS and per-agent rows for its own agents only.
+__global__ void k_observe_part(DevParams P, LatArgs lat, const float *p_g, const float *dp_g, const float *grid_g,
+                               const int *ng_g, const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g,
+                               float *obs_g, float *rew_g, int *sensed_g, int *occup_g, double *stats_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nthr = P.rows, row = threadIdx.x, e = blockIdx.x / P.parts, part = blockIdx.x % P.parts, i = part * nthr + row;
+    const int n_a = P.n_a;
+    const bool active = i < n_a;
+    EnvLds<float> L = carve<float>(smem, P, 0);                             // (P.state_rows = 2: no velocity arrays)
+    STAMP(3);
+    const int n_g = clamp_ng(ng_g[e], P.n_g_max);
+    const double l_cell = lcell_g[e];
+    for (int c = row; c < P.NGP; c += nthr) {
+        float x = 1e30f, y = 1e30f;
+        if (c < n_g) { x = grid_g[(size_t)e * 2 * P.n_g_max + c]; y = grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c]; }
+        L.gx[c] = x; L.gy[c] = y;
+    }
+    for (int a = row; a < P.SL; a += nthr) {
+        float x = 1e30f, y = 1e30f;                                          // unused slots: far away
+        if (a < n_a) { const size_t b = (size_t)e * 2 * n_a; x = p_g[b + a]; y = p_g[b + n_a + a]; }
+        L.px[a] = x; L.py[a] = y;
+    }
+    L.vx = const_cast<float *>(dp_g) + (size_t)e * 2 * n_a; L.vy = L.vx + n_a;   // velocities (own and the six neighbours') straight from memory
+    int sid = lat.shape_id[e];
+    sid = sid < 0 ? 0 : (sid >= lat.n_shapes ? lat.n_shapes - 1 : sid);
+    const asm_lattice_shape *sh = lat.shapes + sid;
+    for (int k = row; k < ASM_LAT_TAB_BYTES / 16; k += nthr) reinterpret_cast<uint4 *>(L.lat)[k] = reinterpret_cast<const uint4 *>(sh)[k];
+    LatView LV;
+    LV.tab = L.lat; LV.cbx = reinterpret_cast<const float *>(L.lat + ASM_LAT_TAB_BYTES); LV.cby = LV.cbx + ASM_LAT_NB;
+    LV.cols = sh->cols; LV.rows = sh->rows; LV.nb = sh->n_boundary;
+    LV.x0 = sh->x0; LV.y0 = sh->y0; LV.invl = 1.0 / sh->l_cell;
+    LV.c = lat.xform[(size_t)e * 4]; LV.s = lat.xform[(size_t)e * 4 + 1]; LV.ox = lat.xform[(size_t)e * 4 + 2]; LV.oy = lat.xform[(size_t)e * 4 + 3];
+    __syncthreads();
+    for (int k = row; k < ASM_LAT_NB; k += nthr) {                           // published by the barriers of the bin build
+        float x = 1e30f, y = 1e30f;
+        if (k < LV.nb) { const int c = sh->boundary[k]; x = L.gx[c]; y = L.gy[c]; }
+        const_cast<float *>(LV.cbx)[k] = x; const_cast<float *>(LV.cby)[k] = y;
+    }
+    DevParams Q = P; Q.n_g_e = n_g; Q.part = part;
+    observe<float>(Q, L, active, e, i, row, nthr, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+                   stats_g, 0, &LV);
+}
+
+// The statistics of a split step (see swarm_stats), recomputed per agent from what the part launch wrote: reward,
+// in-shape flag, distance to the nearest cell, distance to the nearest other agent (the first listed neighbour, or a
+// scan over everybody when none is within sensing range).  One workgroup of SL threads per environment.
+__global__ void k_swarm_stats(DevParams P, const float *p_g, const float *grid_g, const int *nbr_g, const int *inflag_g,
+                              const int *nearest_g, const float *rew_g, double *stats_g)
+{
+    __shared__ double part[16 * 8];
+    __shared__ float sx[ASM_MAX_AGENTS], sy[ASM_MAX_AGENTS];
+    const int e = blockIdx.x, i = threadIdx.x, n_a = P.n_a;
+    const bool active = i < n_a;
+    double reward = 0.0, dmin = 0.0, nn_min = __builtin_inf();
+    bool in_flag = false;
+    if (active) { sx[i] = p_g[(size_t)e * 2 * n_a + i]; sy[i] = p_g[(size_t)e * 2 * n_a + n_a + i]; }
+    __syncthreads();
+    if (active) {
+        const double px = (double)sx[i], py = (double)sy[i];
+        reward = (double)rew_g[(size_t)e * n_a + i];
+        in_flag = inflag_g[(size_t)e * n_a + i] != 0;
+        int c = nearest_g[(size_t)e * n_a + i];
+        c = c < 0 ? 0 : (c >= P.n_g_max ? P.n_g_max - 1 : c);
+        const double rx = (double)grid_g[(size_t)e * 2 * P.n_g_max + c] - px, ry = (double)grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c] - py;
+        dmin = sqrt(rx * rx + ry * ry);
+        const int j = nbr_g[((size_t)e * n_a + i) * 6];
+        double s0 = 0.0;
+        if (j >= 0 && j < n_a) { const double dx = (double)sx[j] - px, dy = (double)sy[j] - py; s0 = dx * dx + dy * dy; }
+        if (s0 > 0.0) nn_min = s0;
+        else
+            for (int k = 0; k < n_a; ++k) {
+                const double qx = (double)sx[k] - px, qy = (double)sy[k] - py, su = qx * qx + qy * qy;
+                if (su != 0 && su < nn_min) nn_min = su;
+            }
+    }
+    swarm_stats(P, part, i, active, e, reward, dmin, in_flag, nn_min, nullptr, -1.0, stats_g);
 }
 
 // ENV:151-218 with counter-based draws (draw order: shape, angle, 2 discarded, offset
@@ -747,7 +938,7 @@ __global__ void k_reset(DevParams P, uint64_t seed, uint32_t episode, int64_t en
     if (P.state_only) return;                                       // the caller observes the new state with k_step_fast
     __syncthreads();
     DevParams Q = P; Q.n_g_e = n_g; Q.want_stats = 0; Q.want_reward = 0;
-    observe<S>(Q, L, active, e, i, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, nullptr, sensed_g, occup_g,
+    observe<S>(Q, L, active, e, i, i, P.SL, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, nullptr, sensed_g, occup_g,
                nullptr, 0);
 }
 

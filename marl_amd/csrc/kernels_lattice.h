@@ -161,6 +161,39 @@ struct LatView {
     double x0, y0, invl, c, s, ox, oy;
 };
 
+// The lattice view of the agent at (px, py) in environment view V.
+__device__ __forceinline__ LatLane lat_lane_of(const DevParams &P, const LatView &V, bool active, double px, double py)
+{
+    LatLane A;
+    const double rxp = px - V.ox, ryp = py - V.oy;
+    const double cxl = V.c * rxp - V.s * ryp, cyl = V.s * rxp + V.c * ryp;
+    double ud = (cxl - V.x0) * V.invl, vd = (cyl - V.y0) * V.invl;
+    ud = fmin(fmax(ud, -1000.0), 1000.0); vd = fmin(fmax(vd, -1000.0), 1000.0);
+    const double ur = rint(ud), vr = rint(vd);
+    A.ub = (int)ur; A.vb = (int)vr; A.fu = (float)(ud - ur); A.fv = (float)(vd - vr);
+    A.inr = active && A.ub >= -7 && A.ub <= V.cols + 6 && A.vb >= -7 && A.vb <= V.rows + 6;
+    const double Rd = P.d_sen * V.invl, Rod = P.r_avoid * 0.5 * V.invl;
+    const float invl_f = (float)V.invl;
+    A.R2 = (float)(Rd * Rd); A.Ro2 = (float)(Rod * Rod);
+    A.band = P.lat_cb * (float)Rd * invl_f + 4e-6f * A.R2;
+    A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
+    return A;
+}
+
+// Occupancy and coverage bits (CPP:190, WRAP:67) of one agent alone: the rows |k| <= lat_KO of the lattice pass.  For
+// the agents whose sensed cells another workgroup lists (an environment split over several workgroups).
+__device__ __forceinline__ void lat_occupancy_lane(const DevParams &P, const LatView &V, float pxf, float pyf, const float *gx,
+                                                   const float *gy, unsigned *occ, unsigned *cov)
+{
+    const double px = pxf, py = pyf;
+    LatLane A = lat_lane_of(P, V, true, px, py);
+    if (!A.inr) return;
+    A.R2 = -1.f;                                                    // no sensed run: lat_row then only reads the table
+    for (int k = -P.lat_KO; k <= P.lat_KO; ++k)
+        if (lat_row(P, A, V.tab, k, true, V.cols, V.rows, nullptr, occ, cov) & 2u)
+            lat_row_exact<false>(P, V.tab, A.vb, k, A.ub, 4, V.cols, V.rows, px, py, gx, gy, nullptr, occ, cov);
+}
+
 // Whole cell pass of one agent on the lattice: sensed mask (the lane's own mask row, cleared here), occupancy and
 // coverage bits, nearest cell (first minimum).  Same results as cell_pass_words.
 __device__ __forceinline__ int lat_cell_pass_lane(const DevParams &P, const LatView &V, bool active, float pxf, float pyf,
@@ -168,21 +201,7 @@ __device__ __forceinline__ int lat_cell_pass_lane(const DevParams &P, const LatV
 {
     const double px = pxf, py = pyf;
     for (int w = 0; w < P.W; ++w) mrow[w] = 0;
-    LatLane A;
-    {
-        const double rxp = px - V.ox, ryp = py - V.oy;
-        const double cxl = V.c * rxp - V.s * ryp, cyl = V.s * rxp + V.c * ryp;
-        double ud = (cxl - V.x0) * V.invl, vd = (cyl - V.y0) * V.invl;
-        ud = fmin(fmax(ud, -1000.0), 1000.0); vd = fmin(fmax(vd, -1000.0), 1000.0);
-        const double ur = rint(ud), vr = rint(vd);
-        A.ub = (int)ur; A.vb = (int)vr; A.fu = (float)(ud - ur); A.fv = (float)(vd - vr);
-        A.inr = active && A.ub >= -7 && A.ub <= V.cols + 6 && A.vb >= -7 && A.vb <= V.rows + 6;
-        const double Rd = P.d_sen * V.invl, Rod = P.r_avoid * 0.5 * V.invl;
-        const float invl_f = (float)V.invl;
-        A.R2 = (float)(Rd * Rd); A.Ro2 = (float)(Rod * Rod);
-        A.band = P.lat_cb * (float)Rd * invl_f + 4e-6f * A.R2;
-        A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
-    }
+    const LatLane A = lat_lane_of(P, V, active, px, py);
     unsigned und = 0;                                               // 2 bits per row, 15 rows
 #pragma unroll 1
     for (int t = 0; t < 15; ++t) {

@@ -13,15 +13,16 @@ def lists_off():
     """Call to run the following launches without cell lists; restored afterwards."""
     from marl_amd import _lib
     lib = _lib.load()
-    yield lambda off: lib.asm_set_step_schedule(4 + 16 if off else -1)
+    yield lambda off: lib.asm_set_step_schedule(4 + int(off) if off else -1)
     lib.asm_set_step_schedule(-1)
 
 
-def _both(torch, env, lists_off, fn, tag):
-    """fn(env) from the same state with and without cell lists; returns with the cell-list results in place."""
+def _both(torch, env, lists_off, fn, tag, off=16):
+    """fn(env) from the same state without (schedule + off: 16 no cell lists, hence no split either; 32 no split) and
+    with the default schedule; returns with the default schedule's results in place."""
     state = {k: getattr(env, k).clone() for k in ("p", "dp", "neighbor_index", "in_flags", "nearest_cell", "stats")}
-    lists_off(True)
-    assert env.step_schedule() & 64 == 0
+    lists_off(off)
+    assert env.step_schedule() & (64 if off == 16 else 128) == 0
     fn(env)
     want = {k: getattr(env, k).clone() for k in NAMES + ("stats",)}
     for k, v in state.items():
@@ -104,3 +105,33 @@ def test_cell_lists_other_geometry(torch_cuda, lists_off):
             act = env.random_actions(step=t)
             _both(torch, env, lists_off, lambda e: e.step(act), f"{ctor} {over} step {t}")
         teacher_forced_step(env, cfg, rng.uniform(-1, 1, (3, 2, 400)).astype(np.float32), f"{ctor} {over} vs oracle")
+
+
+@pytest.mark.parametrize("n_a,E", [(512, 5), (700, 3), (1024, 3)])
+def test_split_step_equals_one_workgroup_per_environment(torch_cuda, lists_off, n_a, E):
+    """512 agents and more on the lattice path: the step as three launches with the observation split over 256-agent
+    workgroups against the single launch (asm_set_step_schedule(+32)), every output and the statistics bit for bit,
+    random and packed into the shapes; then against the oracle."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, teacher_forced_step
+    from marl_amd.batched import BatchedAssemblyEnv
+    env = BatchedAssemblyEnv(E, n_a, seed=n_a, keep_indices=True)
+    env.reset()
+    assert env.step_schedule() & (32 + 64 + 128) == 32 + 64 + 128
+    for t in range(5):
+        act = env.random_actions(step=t)
+        _both(torch, env, lists_off, lambda e: e.step(act), f"random {t}", off=32)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cell = (torch.rand(E, n_a, device="cuda", generator=g) * env.n_g[:, None]).long()
+    pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a)) + 0.03 * torch.randn(E, 2, n_a, device="cuda", generator=g)
+    env.p.copy_(pos); env.observe()
+    cfg = cfg_from_env(env)
+    rng = np.random.default_rng(n_a)
+    for t in range(3):
+        act = torch.from_numpy(rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)).cuda()
+        _both(torch, env, lists_off, lambda e: e.step(act), f"packed {t}", off=32)
+    assert int((env.sensed_index >= 0).sum(-1).max()) == 80
+    teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), "split vs oracle")
+    env.invalidate_lattice()                                              # no lattice description: back to the single launch
+    assert env.step_schedule() & 128 == 0
+    teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), "after invalidate vs oracle")
