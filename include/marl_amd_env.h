@@ -126,8 +126,9 @@ int asm_abi_version(void);
 /* Tuning / test knob: which kernel asm_batch_*_f32 runs for environments of at most 32 agents: 4 (default), 2 or 1
  * wavefronts per workgroup of the multi-wave step kernel, 0 = the generic kernel, -1 = back to the default (the
  * MARL_AMD_FAST_T environment variable, read once per process, else 4).  + 16: large swarms (256 agents and more) run
- * their pair passes (contacts, nearest neighbours) over all agents instead of through cell lists.  All produce the
- * same results. */
+ * their pair passes (contacts, nearest neighbours) over all agents instead of through cell lists.  + 32: large swarms
+ * of 512 agents and more on the lattice path step in three launches (dynamics; observation split over 256-agent
+ * workgroups; statistics) instead of one.  All produce the same results. */
 void asm_set_step_schedule(int waves);
 const char *asm_last_error(void);
 /* Number of visible HIP devices, or a negative HIP error code. */
@@ -313,8 +314,8 @@ int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *cou
 
 /* Self-test hook: which kernel asm_batch_step_f32 would launch for these arguments: waves per workgroup of the
  * multi-wave kernel (4, 2, 1) or 0 for the generic kernel, plus 16 if its lattice path is taken, plus 32 if the
- * generic kernel's (large swarms), plus 64 if the pair passes go through cell lists; negative on bad arguments.
- * Host-side only. */
+ * generic kernel's (large swarms), plus 64 if the pair passes go through cell lists, plus 128 for the three-launch
+ * step; negative on bad arguments.  Host-side only. */
 int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lattice /*nullable*/);
 
 /* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the

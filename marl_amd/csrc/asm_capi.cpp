@@ -59,8 +59,9 @@ int pow2_ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // MARL_AMD_FAST_T (tuning / test knob: waves per workgroup of k_step_fast, 0 = generic kernel), read once per process
 // asm_set_step_schedule() overrides it at run time (tests compare the schedules within one process).
-// Bit 4 of the value (+16): the large-swarm pair passes without their cell lists; bit 5 (+32): large swarms as one
-// workgroup per environment even where the step could split them.
+// Bit 4 of the value (+16): the large-swarm pair passes without their cell lists; bit 5 (+32): the step of a large
+// swarm as three launches with the observation split over 256-agent workgroups (measured slower than the single
+// launch at every batch size tried, so it is off unless asked for).
 std::atomic<int> g_schedule_override{-1};
 int schedule_setting()
 {
@@ -70,7 +71,7 @@ int schedule_setting()
 }
 int fast_t_setting() { return schedule_setting() & 15; }
 bool cell_lists_off() { return (schedule_setting() & 16) != 0; }
-bool split_off() { return (schedule_setting() & 32) != 0; }
+bool split_on() { return (schedule_setting() & 32) != 0; }
 
 // Launch geometry + thresholds.  state_bytes = sizeof(S).
 int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParams *out);
@@ -250,7 +251,7 @@ bool lattice_usable_swarm(const asm_lattice *lat, const asm_params *prm, DevPara
 // launch_step_split): on the lattice path with cell lists only.  Fills the part workgroups' parameters.
 bool split_usable(DevParams *P, DevParams *part)
 {
-    if (P->lat != 2 || !P->bins || P->SL < 512 || P->W > 32 || split_off()) return false;
+    if (P->lat != 2 || !P->bins || P->SL < 512 || P->W > 32 || !split_on()) return false;
     DevParams Q = *P;
     Q.rows = 256; Q.parts = P->SL / 256; Q.state_rows = 2;
     if (!swarm_layout(&Q, sizeof(float)) || !Q.bins) return false;

@@ -111,14 +111,6 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 unsigned K[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) K[q] = 0xFFFFFFFFu;
-                auto insert_exact = [&](int j, double s) {                      // (s, j) ascending: ties keep the lower index
-                    double ks = s; int kj = j; bool placed = false;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        if (placed || ks < s6[q] || (ks == s6[q] && kj < j6[q])) {
-                            const double ts = s6[q]; const int tj = j6[q]; s6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true;
-                        }
-                };
                 if (BV) {
                     // Rows of bins nearest first; once eight candidates are held, only keys below the eighth can still
                     // enter the list, so the screen's threshold follows it down and the rows (and the bins of a row)
@@ -175,40 +167,47 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                     j6[q] = there ? (int)(K[q] & 1023u) : -1;
                 }
                 const bool redo = amb && K[5] != 0xFFFFFFFFu && (K[7] >> 10) - (K[5] >> 10) < 2u;
-                if (amb && !redo) {                                             // the first seven, exactly
+                if (amb) {                                                      // rare paths: exact distances, (s, j) ascending (ties keep the lower index)
+                    double e6[6];
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) j6[q] = -1;
+                    for (int q = 0; q < 6; ++q) { e6[q] = __builtin_inf(); j6[q] = -1; }
+                    auto insert_exact = [&](int j, double s) {
+                        double ks = s; int kj = j; bool placed = false;
 #pragma unroll
-                    for (int q = 0; q < 7; ++q)
-                        if (K[q] != 0xFFFFFFFFu) {
-                            const int j = (int)(K[q] & 1023u);
-                            const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
-                            const double s = dx * dx + dy * dy;                 // CPP:641
-                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
-                        }
-                }
-                if (redo && BV) {                                               // very rare
+                        for (int q = 0; q < 6; ++q)
+                            if (placed || ks < e6[q] || (ks == e6[q] && kj < j6[q])) {
+                                const double ts = e6[q]; const int tj = j6[q]; e6[q] = ks; j6[q] = kj; ks = ts; kj = tj; placed = true;
+                            }
+                    };
+                    if (!redo) {                                                    // the first seven, exactly
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) j6[q] = -1;
-                    bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
-                        const float rx = c.x - pxf, ry = c.y - pyf;
-                        if (__builtin_fmaf(ry, ry, rx * rx) < P.Tsen_hi_f && j != i) {
-                            const double dx = (double)c.x - px, dy = (double)c.y - py;
-                            const double s = dx * dx + dy * dy;                 // CPP:641
-                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
-                        }
-                    });
-                } else if (redo) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) j6[q] = -1;
-                    for (int j0 = 0; j0 < P.SL; j0 += 32) {
-                        unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
-                        if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
-                        while (m) {
-                            const int j = j0 + __ffs(m) - 1; m &= m - 1;
-                            const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
-                            const double s = dx * dx + dy * dy;                 // CPP:641
-                            if (s < P.T_sen) insert_exact(j, s);                // CPP:663
+                        for (int q = 0; q < 7; ++q)
+                            if (K[q] != 0xFFFFFFFFu) {
+                                const int j = (int)(K[q] & 1023u);
+                                const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                                const double s = dx * dx + dy * dy;                 // CPP:641
+                                if (s < P.T_sen) insert_exact(j, s);                // CPP:663
+                            }
+                    }
+                    if (redo && BV) {                                               // very rare
+                        bins_for_each(P, P.bin_s, *BV, pxf, pyf, [&](f32x2 c, int j) {
+                            const float rx = c.x - pxf, ry = c.y - pyf;
+                            if (__builtin_fmaf(ry, ry, rx * rx) < P.Tsen_hi_f && j != i) {
+                                const double dx = (double)c.x - px, dy = (double)c.y - py;
+                                const double s = dx * dx + dy * dy;                 // CPP:641
+                                if (s < P.T_sen) insert_exact(j, s);                // CPP:663
+                            }
+                        });
+                    } else if (redo) {
+                        for (int j0 = 0; j0 < P.SL; j0 += 32) {
+                            unsigned m = pair_screen32(L.px + j0, L.py + j0, pxf, pyf, P.Tsen_hi_f);
+                            if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
+                            while (m) {
+                                const int j = j0 + __ffs(m) - 1; m &= m - 1;
+                                const double dx = (double)L.px[j] - px, dy = (double)L.py[j] - py;
+                                const double s = dx * dx + dy * dy;                 // CPP:641
+                                if (s < P.T_sen) insert_exact(j, s);                // CPP:663
+                            }
                         }
                     }
                 }

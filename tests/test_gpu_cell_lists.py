@@ -18,17 +18,17 @@ def lists_off():
 
 
 def _both(torch, env, lists_off, fn, tag, off=16):
-    """fn(env) from the same state without (schedule + off: 16 no cell lists, hence no split either; 32 no split) and
-    with the default schedule; returns with the default schedule's results in place."""
+    """fn(env) from the same state under schedule 4 + off (16: no cell lists; 32: the three-launch step) and under the
+    default schedule; returns with the default schedule's results in place."""
     state = {k: getattr(env, k).clone() for k in ("p", "dp", "neighbor_index", "in_flags", "nearest_cell", "stats")}
     lists_off(off)
-    assert env.step_schedule() & (64 if off == 16 else 128) == 0
+    assert env.step_schedule() & (64 + 128) == (0 if off == 16 else 64 + 128)
     fn(env)
     want = {k: getattr(env, k).clone() for k in NAMES + ("stats",)}
     for k, v in state.items():
         getattr(env, k).copy_(v)
     lists_off(False)
-    assert env.step_schedule() & 64 == 64
+    assert env.step_schedule() & (64 + 128) == 64
     fn(env)
     for k in NAMES:
         assert torch.equal(getattr(env, k), want[k]), f"{tag}: {k}"
@@ -110,14 +110,14 @@ def test_cell_lists_other_geometry(torch_cuda, lists_off):
 @pytest.mark.parametrize("n_a,E", [(512, 5), (700, 3), (1024, 3)])
 def test_split_step_equals_one_workgroup_per_environment(torch_cuda, lists_off, n_a, E):
     """512 agents and more on the lattice path: the step as three launches with the observation split over 256-agent
-    workgroups against the single launch (asm_set_step_schedule(+32)), every output and the statistics bit for bit,
+    workgroups (asm_set_step_schedule(+32)) against the single launch, every output and the statistics bit for bit,
     random and packed into the shapes; then against the oracle."""
     torch = torch_cuda
     from gpu_util import cfg_from_env, teacher_forced_step
     from marl_amd.batched import BatchedAssemblyEnv
     env = BatchedAssemblyEnv(E, n_a, seed=n_a, keep_indices=True)
     env.reset()
-    assert env.step_schedule() & (32 + 64 + 128) == 32 + 64 + 128
+    assert env.step_schedule() & (32 + 64 + 128) == 32 + 64
     for t in range(5):
         act = env.random_actions(step=t)
         _both(torch, env, lists_off, lambda e: e.step(act), f"random {t}", off=32)
@@ -131,6 +131,7 @@ def test_split_step_equals_one_workgroup_per_environment(torch_cuda, lists_off, 
         act = torch.from_numpy(rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32)).cuda()
         _both(torch, env, lists_off, lambda e: e.step(act), f"packed {t}", off=32)
     assert int((env.sensed_index >= 0).sum(-1).max()) == 80
+    lists_off(32)
     teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), "split vs oracle")
     env.invalidate_lattice()                                              # no lattice description: back to the single launch
     assert env.step_schedule() & 128 == 0

@@ -15,6 +15,7 @@ from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 n_a = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 env = BatchedAssemblyEnv(E, n_a)
+env.lib.asm_set_step_schedule(4 + 32)
 env.reset()
 assert env.step_schedule() & 128
 for t in range(30):
