@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
 cd $R
 b() { timeout -k 10 300 python3 bench.py "$@"; }
 b > $O/bench_default.json 2> $O/bench_default.err
+b --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2>> $O/bench_default.err
 : > $O/bench_variants.jsonl
 for args in "--regime packed" "--periodic" "--keep-indices sensed" "--keep-indices both" "--envs-per-gpu 8192" \
             "--envs-per-gpu 256 --agents 1024 --streams 1" "--envs-per-gpu 256 --agents 1024 --streams 2"; do
@@ -16,6 +17,10 @@ for args in "--regime packed" "--periodic" "--keep-indices sensed" "--keep-indic
 done
 line=$(MARL_AMD_NO_LATTICE=1 b --no-cpu-baseline 2>> $O/bench_variants.err)
 python3 -c "import json,sys; d=json.loads(sys.argv[1]); d={'bench_args': sys.argv[2], **d}; print(json.dumps(d))" "$line" "MARL_AMD_NO_LATTICE=1 --no-cpu-baseline (every cell tested against every agent)" >> $O/bench_variants.jsonl
+for v in 20 36; do                                       # 256 x 1024 without cell lists (+16) / as three launches (+32)
+  line=$(MARL_AMD_FAST_T=$v b --no-cpu-baseline --envs-per-gpu 256 --agents 1024 --streams 2 2>> $O/bench_variants.err)
+  python3 -c "import json,sys; d=json.loads(sys.argv[1]); d={'bench_args': sys.argv[2], **d}; print(json.dumps(d))" "$line" "MARL_AMD_FAST_T=$v --no-cpu-baseline --envs-per-gpu 256 --agents 1024 --streams 2" >> $O/bench_variants.jsonl
+done
 echo bench-done
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -- python3 $R/bench.py --no-cpu-baseline > $O/trace_default.log 2>&1
