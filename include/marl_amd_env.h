@@ -312,6 +312,21 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
 int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *counter_dev /*nullable*/, int64_t lo,
                             int64_t hi, int N, int64_t *index, void *stream);
 
+/* Rollout inference of the policy network for every agent of every environment, on the matrix cores (bf16 operands, fp32
+ * accumulation): what MADDPG.step -> DDPGAgent.step -> MLPNetwork.forward compute one environment at a time
+ * (maddpg.py:72-87, agents.py:69-96 without the exploration noise, networks.py:33-44: Linear - leaky_relu three times,
+ * Linear - tanh).  obs: [E][obs_dim][n_a] as the step writes it; act: [E][act_dim][n_a] as the step reads it.  Weights:
+ * one 16-byte fragment of 8 bf16 per lane, packed by the caller (marl_amd/policy_kernel.py::pack_policy):
+ *   w1 [K1][H/32][64][8] (k-step s, row tile m, lane l, element j), K1 = ceil(obs_dim / 16):
+ *       W1[32 m + (l & 31)][16 s + 8 (l >> 5) + j]
+ *   w2, w3 [H/16][H/32][64][8]: W[32 m + (l & 31)][32 (s >> 1) + 16 (s & 1) + 8 (j >> 2) + 4 (l >> 5) + (j & 3)]
+ *   w4 [H/16][1][64][8]: the same with the act_dim output rows padded to 32
+ * (zero beyond the matrices' bounds), bias: [3 H + 32] floats (b1, b2, b3, b4 padded).  H = 32, 64, 128 or 256,
+ * act_dim <= 32.  Values differ from the float32 network by bf16 rounding of weights and activations (about 1e-2). */
+int asm_policy_mlp_forward_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
+                                const void *w2, const void *w3, const void *w4, const float *bias, float *act,
+                                void *stream);
+
 /* Self-test hook: which kernel asm_batch_step_f32 would launch for these arguments: waves per workgroup of the
  * multi-wave kernel (4, 2, 1) or 0 for the generic kernel, plus 16 if its lattice path is taken, plus 32 if the
  * generic kernel's (large swarms), plus 64 if the pair passes go through cell lists, plus 128 for the three-launch

@@ -47,7 +47,8 @@ EXPORTS = ["_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "c
            "asm_batch_observe_f32", "asm_batch_step_f32", "asm_batch_reset_f32",
            "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_batch_rule_actions_f32", "asm_replay_gather_f32", "asm_replay_draw_indices",
            "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err", "asm_get_observation_noalloc", "asm_lattice_build",
-           "asm_batch_check_lattice", "asm_set_step_schedule", "asm_debug_step_schedule"]
+           "asm_batch_check_lattice", "asm_set_step_schedule", "asm_debug_step_schedule",
+           "asm_policy_mlp_forward_bf16"]
 
 _lib = None
 
@@ -103,6 +104,8 @@ def load() -> C.CDLL:
     lib.asm_get_observation_noalloc.restype = C.c_int
     lib.asm_debug_step_schedule.restype = C.c_int
     lib.asm_debug_step_schedule.argtypes = [PP, i32, LP]
+    lib.asm_policy_mlp_forward_bf16.restype = C.c_int
+    lib.asm_policy_mlp_forward_bf16.argtypes = [i32] * 5 + [vp] * 8
     lib.asm_set_step_schedule.restype = None
     lib.asm_set_step_schedule.argtypes = [C.c_int]
     if lib.asm_abi_version() != ABI_VERSION:

@@ -62,6 +62,7 @@ __device__ __forceinline__ void wrap_rel(double &x, double &y, double hw, double
 #include "kernels_fast.h"
 #include "kernels_aux.h"
 #include "kernels_compat.h"
+#include "kernels_policy.h"
 
 // ---------------------------------------------------------------------------------
 // launchers
@@ -219,6 +220,32 @@ int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ri
                        act_ring, prior_ring, rew_ring, index, N, obs_out, act_out, rew_out, next_out, prior_out);
     LAUNCH_CHECK();
     return 0;
+}
+
+int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1, const void *w2,
+                      const void *w3, const void *w4, const float *bias, float *act, hipStream_t st)
+{
+    const int TPE = (n_a + 31) / 32, ntiles = E * TPE, K1 = (obs_dim + 15) / 16;
+    const dim3 grid((unsigned)((ntiles + 7) / 8)), block(256);
+    const int HT = hidden / 32;
+    // two LDS buffers of this many 1 KiB fragments: half the first layer, half a hidden layer, the whole output layer
+    const int half_frags = HT * std::max({(K1 + 1) / 2, HT, 2});
+    const size_t lds = (size_t)2048 * half_frags + 4 * (3 * (size_t)hidden + 32);
+    if (lds > 160 * 1024) return -1;
+    auto go = [&](auto kernel) {
+        if (int rc = set_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, n_a, obs_dim, K1, act_dim, TPE, ntiles, half_frags, obs, (const uint4 *)w1,
+                           (const uint4 *)w2, (const uint4 *)w3, (const uint4 *)w4, bias, act);
+        LAUNCH_CHECK();
+        return 0;
+    };
+    switch (hidden) {
+    case 32: return go(k_policy_mlp<1>);
+    case 64: return go(k_policy_mlp<2>);
+    case 128: return go(k_policy_mlp<4>);
+    case 256: return go(k_policy_mlp<8>);
+    default: return -1;
+    }
 }
 
 #ifdef ASM_DIAG

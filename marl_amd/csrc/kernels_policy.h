@@ -1,0 +1,206 @@
+// Rollout inference of the shared policy network on the matrix cores: the four-layer MLP of networks.py:6-44
+// (Linear - leaky_relu x 3, Linear - tanh) applied to every agent's observation column, bf16 operands, fp32 accumulation.
+// Part of the single translation unit asm_kernels.hip (included there, inside namespace asmenv); not a stand-alone header.
+//
+// Orientation.  The environment writes observations as obs[e][feature][agent] (ENV.step's (obs_dim, n_a) per
+// environment), which is X^T with the agents contiguous.  Every layer is computed as  H^T = W . X^T : the weight matrix
+// [out][in] is the A operand of v_mfma_f32_32x32x16_bf16, a tile of 32 agents the B operand.  The 32 x 32 result has
+// its column (agent) on the lane and its rows (features) in the 16 accumulator registers, and the next layer sums over
+// exactly that row index, so the activated accumulator, converted to bf16 pairwise, IS the next layer's B operand:
+// registers 8s .. 8s+7 of row tile m form the fragment of k-step 2m + s, holding the features
+// 32m + 16s + 8(j >> 2) + 4(lane >> 5) + (j & 3), j = 0..7.  The weights are packed on the host in that k order (and in
+// natural order for the first layer), one 16-byte fragment per lane, k-step major, so a wave's weight read is 1 KiB
+// contiguous and half a layer (the first or the second half of its k-steps) is one contiguous block.  No activation
+// ever touches LDS or memory.
+//
+// A wave owns two tiles of 32 agents (one environment of up to 32 agents per tile; larger swarms take several tiles
+// per environment) so that every weight fragment feeds two MFMAs; with hidden width 256 that is 2 x 8 x 16 accumulator
+// registers plus 2 x 16 x 4 operand registers per lane: one wave per SIMD, the unified 512-register file.
+//
+// Weights reach the four waves of a workgroup through LDS, copied by global_load_lds_dwordx4 (LDS destination =
+// wave-uniform base + 16 bytes per lane, i.e. the packed layout itself; no registers): the whole first layer before
+// the first MFMA, the hidden layers half a layer at a time in two buffers, the copy of one half running under the
+// MFMAs of the other, one barrier per half.  (The first layer is not split: while such a copy is in flight the
+// compiler drains every outstanding load before any ordinary load's result is used, which would stall the observation
+// prefetch below.)  A wave alone on its SIMD cannot hide a weight fetch from memory per MFMA pair (the first version of
+// this kernel did that and ran at the speed of the PyTorch path), nor an LDS read per MFMA pair: the fragments of a
+// k-step are read one k-step ahead (two register sets, scheduling barriers keep the reads in front of the MFMAs they
+// overlap with).  The first layer's operands, 8 strided observation rows per lane and k-step, are fetched from memory
+// four k-steps ahead.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// (f32x2: kernels_common.h)
+
+// HT: hidden width / 32.  w1: [K1][HT][64] fragments (natural k order, K1 = ceil(obs_dim / 16)); w2, w3: [2 HT][HT][64],
+// w4: [2 HT][1][64] (output rows padded to 32), all in the accumulator's k order; bias: [3 * 32 HT + 32] floats.
+// Dynamic LDS: two buffers of half_frags KiB, half_frags = HT x max(ceil(K1 / 2), HT, 2), then the biases.
+template <int HT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_frags, const float *obs_g, const uint4 *w1,
+                  const uint4 *w2, const uint4 *w3, const uint4 *w4, const float *bias, float *out_g)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int H = 32 * HT, KS = 2 * HT, KH = HT, PF = 4;           // KH: k-steps per half of a hidden layer
+    uint4 *const buf0 = reinterpret_cast<uint4 *>(smem), *const buf1 = buf0 + (size_t)half_frags * 64;
+    float *const bl = reinterpret_cast<float *>(buf1 + (size_t)half_frags * 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int t0 = (blockIdx.x * 4 + wave) * 2;
+    int env[2], agent[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = t0 + u < ntiles ? t0 + u : 0;
+        env[u] = t / TPE; agent[u] = (t % TPE) * 32 + r;
+        ok[u] = t0 + u < ntiles && agent[u] < n_a;
+    }
+    // nfrag fragments from w into dst, every wave a quarter of them, all in flight at once
+    auto dma = [&](const uint4 *w, int nfrag, uint4 *dst) __attribute__((always_inline)) {
+        for (int f = wave; f < nfrag; f += 4)
+            __builtin_amdgcn_global_load_lds(w + f * 64 + lane, (__attribute__((address_space(3))) void *)(dst + f * 64), 16, 0, 0);
+    };
+    dma(w1, K1 * HT, buf0);                                            // the whole first layer (it spans both buffers)
+    for (int k = threadIdx.x; k < 3 * H + 32; k += 256) bl[k] = bias[k];
+
+    // ---- layer 1: operands straight from the observation rows (8 consecutive features of one agent per lane) ----
+    const float *col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) col[u] = obs_g + (size_t)env[u] * D * n_a + agent[u];
+    // xb[p]: the 16 observation values (2 tiles x 8 features) of a k-step, PF k-steps in flight
+    float xb[PF][16];
+#define POLICY_FETCH(S, P)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+            const int k = 16 * (S) + 8 * h + j;                                                         \
+            xb[P][u * 8 + j] = (ok[u] && k < D) ? col[u][(size_t)k * n_a] : 0.f;                        \
+        }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) { POLICY_FETCH(p, p) }                 // (k-steps beyond K1 read nothing: k >= D)
+
+    f32x16 acc[2][HT];
+    f32x16 zero;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zero[q] = 0.f;
+    // weight fragments: a k-step's HT fragments are read from LDS in groups of GM, one group ahead of the MFMAs that use
+    // them (two register sets; 2 GM MFMAs = 64 GM cycles cover the read)
+    constexpr int GM = HT >= 2 ? HT / 2 : 1, NG = HT / GM;
+    bf16x8 Aq[2][GM];
+    __syncthreads();                                                   // the first layer's weights and the biases are in LDS
+#pragma unroll
+    for (int u = 0; u < 2; ++u)                                        // (cleared after the wait: nothing to keep alive across it)
+#pragma unroll
+        for (int m = 0; m < HT; ++m) acc[u][m] = zero;
+#pragma unroll
+    for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, buf0[m * 64 + lane]);
+    for (int s0 = 0; s0 < K1; s0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int s = s0 + p;
+            if (s < K1) {
+                bf16x8 B[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) B[u][j] = (__bf16)xb[p][u * 8 + j];
+                POLICY_FETCH(s + PF, p)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int cur = (p * NG + g) & 1;                  // (PF * NG is even: the parity carries over the outer loop)
+                    const int nf = (g + 1 < NG) ? s * HT + (g + 1) * GM : (s + 1 < K1 ? (s + 1) * HT : s * HT);
+#pragma unroll
+                    for (int m = 0; m < GM; ++m) Aq[cur ^ 1][m] = __builtin_bit_cast(bf16x8, buf0[(nf + m) * 64 + lane]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < GM; ++m) {
+                        acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[0], acc[0][g * GM + m], 0, 0, 0);
+                        acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[1], acc[1][g * GM + m], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#undef POLICY_FETCH
+
+    // bias + leaky_relu (slope 0.01, F.leaky_relu's default: max(v, 0.01 v)) on the accumulators, packed as the next
+    // layer's operands.  (Starting the sums from the bias instead, as the first MFMA's C operand, costs more registers
+    // than the adds it saves: measured slower.)
+    bf16x8 F[2][KS];
+    auto activate = [&](const float *b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b + 32 * m + 8 * g + 4 * h);    // rows 8g + 4h .. + 3
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int q = 4 * g + c;
+                        const float v = acc[u][m][q] + b4[c];
+                        F[u][2 * m + (q >> 3)][q & 7] = (__bf16)__builtin_fmaxf(v, 0.01f * v);
+                    }
+                __builtin_amdgcn_sched_barrier(0);                     // (keeps the live temporaries of this pass few)
+            }
+    };
+    // k-steps [sa, sa + KH) of a hidden layer from the fragments in wb
+    auto hidden_part = [&](const uint4 *wb, int sa) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, wb[m * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < KH; ++t)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cur = (t * NG + g) & 1;
+                if (t * NG + g + 1 < KH * NG) {
+#pragma unroll
+                    for (int m = 0; m < GM; ++m)
+                        Aq[cur ^ 1][m] = __builtin_bit_cast(bf16x8, wb[((t * NG + g + 1) * GM + m) * 64 + lane]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < GM; ++m) {                          // the layer's first k-step starts the sums
+                    const bool first = sa == 0 && t == 0;
+                    acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], F[0][sa + t], first ? zero : acc[0][g * GM + m], 0, 0, 0);
+                    acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], F[1][sa + t], first ? zero : acc[1][g * GM + m], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    __syncthreads();                                                   // everybody is done with the first layer's weights
+    dma(w2, KH * HT, buf0);
+    activate(bl);
+    __syncthreads();                                                   // w2's first half is in
+    dma(w2 + (size_t)KH * HT * 64, KH * HT, buf1);
+    hidden_part(buf0, 0);
+    __syncthreads();                                                   // w2's second half is in; buf0 is free
+    dma(w3, KH * HT, buf0);
+    hidden_part(buf1, KH);
+    activate(bl + H);
+    __syncthreads();
+    dma(w3 + (size_t)KH * HT * 64, KH * HT, buf1);
+    hidden_part(buf0, 0);
+    __syncthreads();
+    dma(w4, KS, buf0);
+    hidden_part(buf1, KH);
+    activate(bl + 2 * H);
+    __syncthreads();                                                   // the output layer's weights are in
+
+    // ---- output layer (rows padded to one tile) and tanh ----
+    f32x16 o[2] = {zero, zero};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 Aw = __builtin_bit_cast(bf16x8, buf0[s * 64 + lane]);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[0][s], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[1][s], o[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (ok[u] && row < A)
+                out_g[((size_t)env[u] * A + row) * n_a + agent[u]] = tanhf(o[u][q] + bl[3 * H + row]);
+        }
+}

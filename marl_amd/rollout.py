@@ -96,6 +96,12 @@ class DDPGLearner:
         self.gamma, self.tau = gamma, tau
         self.act_dtype = act_dtype                                         # rollout inference precision; None = float32
         self.niter = 0
+        # bf16 rollouts on a HIP device go through the library's matrix-core kernel (marl_amd/policy_kernel.py) when the
+        # network has a shape it takes; the weights are re-packed after every update
+        self.fused_policy, self._policy_version, self._packed_version = None, 0, 0
+        if act_dtype is torch.bfloat16 and torch.device(device).type == "cuda" and hidden_dim in (32, 64, 128, 256) and act_dim <= 32:
+            from .policy_kernel import FusedPolicyBF16
+            self.fused_policy = FusedPolicyBF16(self.policy)
 
     @torch.no_grad()
     def act(self, obs: torch.Tensor, out: torch.Tensor, noise_scale: float = 0.0, epsilon: float = 0.0,
@@ -105,13 +111,18 @@ class DDPGLearner:
         with probability epsilon the whole team acts uniformly at random, else Gaussian noise is added and the
         action clamped to [-1, 1].  generator: a torch.Generator on the environment's device."""
         E, d, n = obs.shape
-        x = obs.transpose(1, 2).reshape(E * n, d)                          # maddpg.py:84: observations.t()
-        if self.act_dtype is not None:                                     # e.g. torch.bfloat16: MFMA inference for rollouts
-            with torch.autocast("cuda", dtype=self.act_dtype):
-                a = self.policy(x).float()
+        if self.fused_policy is not None and obs.is_contiguous() and out.is_contiguous() and noise_scale <= 0.0 and epsilon <= 0.0:
+            return self._fused(obs, out)                                   # no exploration: the kernel writes the actions in place
+        if self.fused_policy is not None and obs.is_contiguous():
+            a = self._fused(obs, torch.empty_like(out)).transpose(1, 2)    # (E, n, act_dim), as below
         else:
-            a = self.policy(x)
-        a = a.view(E, n, -1)
+            x = obs.transpose(1, 2).reshape(E * n, d)                      # maddpg.py:84: observations.t()
+            if self.act_dtype is not None:                                 # e.g. torch.bfloat16: MFMA inference for rollouts
+                with torch.autocast("cuda", dtype=self.act_dtype):
+                    a = self.policy(x).float()
+            else:
+                a = self.policy(x)
+            a = a.view(E, n, -1)
         if noise_scale > 0.0:                                              # agents.py:91-94
             a = (a + noise_scale * torch.randn(a.shape, device=a.device, generator=generator)).clamp_(-1.0, 1.0)
         if epsilon > 0.0:                                                  # agents.py:87-89, one coin per environment
@@ -119,6 +130,11 @@ class DDPGLearner:
             a = torch.where(coin, torch.empty_like(a).uniform_(-1.0, 1.0, generator=generator), a)
         out.copy_(a.transpose(1, 2))
         return out
+
+    def _fused(self, obs, out):
+        if self._packed_version != self._policy_version:
+            self.fused_policy.repack(); self._packed_version = self._policy_version
+        return self.fused_policy.forward(obs, out)
 
     def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True,
                branch_free: bool = False):
@@ -156,6 +172,7 @@ class DDPGLearner:
         if self.data_parallel:
             self._pol_grads.average(self.group)                            # maddpg.py:179-180
         self.policy_optimizer.step()
+        self._policy_version += 1
         if sync_losses:
             return float(vf_loss.detach()), float(pol_loss.detach())
         return vf_loss.detach(), pol_loss.detach()

@@ -33,6 +33,7 @@ ap.add_argument("--slots", type=int, default=2)
 ap.add_argument("--batch-size", type=int, default=2048)
 ap.add_argument("--graph", action="store_true", help="train phase as a replayed HIP graph (GraphedTrainPhase); single rank")
 ap.add_argument("--act-dtype", choices=["float32", "bfloat16"], default="float32", help="rollout inference precision")
+ap.add_argument("--no-fused", action="store_true", help="bf16 rollouts through PyTorch autocast instead of the library's matrix-core policy kernel")
 a = ap.parse_args()
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,6 +57,8 @@ env = BatchedAssemblyEnv(a.envs, a.agents, device=device, env_id_offset=shard_ra
 rp = DeviceReplay(env, a.episode_length, a.slots, seed=rank)
 learner = DDPGLearner(env.obs_dim_agent, device=device, act_dtype=torch.bfloat16 if a.act_dtype == "bfloat16" else None,
                       data_parallel=world > 1, capturable=a.graph)
+if a.no_fused:
+    learner.fused_policy = None
 graphed = None
 if a.graph:
     from marl_amd.rollout import GraphedTrainPhase
@@ -89,6 +92,7 @@ if rank == 0:
         "workload": f"{a.envs} envs x {a.agents} agents per GPU x {world} GPU(s), {a.episodes} episodes of {a.episode_length} steps, "
                     f"policy/critic MLP 256, 30 updates of {a.batch_size} per episode and rank, replay in HBM "
                     f"({a.slots} episode slots), rollout inference in {a.act_dtype}"
+                    + (" (fused matrix-core kernel)" if learner.fused_policy is not None else "")
                     + (", learner replicas with averaged gradients" if world > 1 else "")
                     + (", train phase replayed from a HIP graph" if a.graph else ""),
         "n_gpus": world,
