@@ -326,6 +326,14 @@ int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *cou
 int asm_policy_mlp_forward_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
                                 const void *w2, const void *w3, const void *w4, const float *bias, float *act,
                                 void *stream);
+/* The same with the exploration of agents.py:86-94 applied in the kernel's epilogue: per environment, with probability
+ * epsilon every agent's action is drawn uniformly from [-1, 1) (:87-89), else Gaussian noise of standard deviation
+ * noise_scale is added (noise.py:29-30) and the action clamped to [-1, 1] (:91-94).  Counter-based draws (Philox4x32-10)
+ * keyed by (seed, env0 + e, agent, output pair, step): the caller advances `step` once per call; the numbers do not
+ * depend on how the environments are split over calls or GPUs.  noise_scale = epsilon = 0: no exploration. */
+int asm_policy_mlp_act_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
+                            const void *w2, const void *w3, const void *w4, const float *bias, float *act,
+                            float noise_scale, float epsilon, uint64_t seed, uint32_t step, int64_t env0, void *stream);
 
 /* Self-test hook: which kernel asm_batch_step_f32 would launch for these arguments: waves per workgroup of the
  * multi-wave kernel (4, 2, 1) or 0 for the generic kernel, plus 16 if its lattice path is taken, plus 32 if the

@@ -538,17 +538,27 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
     return rc ? hip_fail(rc, "asm_replay_gather_f32") : 0;
 }
 
+int asm_policy_mlp_act_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
+                            const void *w2, const void *w3, const void *w4, const float *bias, float *act, float noise_scale,
+                            float epsilon, uint64_t seed, uint32_t step, int64_t env0, void *stream)
+{
+    if (E < 1 || n_a < 1 || obs_dim < 1 || act_dim < 1 || act_dim > 32 || !obs || !w1 || !w2 || !w3 || !w4 || !bias || !act)
+        return fail(1, "asm_policy_mlp_act_bf16: bad arguments");
+    if (!(noise_scale >= 0.f) || !(epsilon >= 0.f))
+        return fail(1, "asm_policy_mlp_act_bf16: noise_scale and epsilon must be >= 0");
+    if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256)
+        return fail(1, "asm_policy_mlp_act_bf16: hidden = %d (supported: 32, 64, 128, 256)", hidden);
+    if ((size_t)(hidden / 32) * std::max(((obs_dim + 15) / 16 + 1) / 2, 2) * 2048 + 4 * (3 * (size_t)hidden + 32) > 160 * 1024)
+        return fail(1, "asm_policy_mlp_act_bf16: obs_dim = %d with hidden = %d: the first layer's weights do not fit the LDS", obs_dim, hidden);
+    int rc = asmenv::launch_policy_mlp(E, n_a, obs_dim, hidden, act_dim, obs, w1, w2, w3, w4, bias, act, noise_scale, epsilon, seed,
+                                       step, env0, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_policy_mlp_act_bf16") : 0;
+}
+
 int asm_policy_mlp_forward_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
                                 const void *w2, const void *w3, const void *w4, const float *bias, float *act, void *stream)
 {
-    if (E < 1 || n_a < 1 || obs_dim < 1 || act_dim < 1 || act_dim > 32 || !obs || !w1 || !w2 || !w3 || !w4 || !bias || !act)
-        return fail(1, "asm_policy_mlp_forward_bf16: bad arguments");
-    if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256)
-        return fail(1, "asm_policy_mlp_forward_bf16: hidden = %d (supported: 32, 64, 128, 256)", hidden);
-    if ((size_t)(hidden / 32) * std::max(((obs_dim + 15) / 16 + 1) / 2, 2) * 2048 + 4 * (3 * (size_t)hidden + 32) > 160 * 1024)
-        return fail(1, "asm_policy_mlp_forward_bf16: obs_dim = %d with hidden = %d: the first layer's weights do not fit the LDS", obs_dim, hidden);
-    int rc = asmenv::launch_policy_mlp(E, n_a, obs_dim, hidden, act_dim, obs, w1, w2, w3, w4, bias, act, (hipStream_t)stream);
-    return rc ? hip_fail(rc, "asm_policy_mlp_forward_bf16") : 0;
+    return asm_policy_mlp_act_bf16(E, n_a, obs_dim, hidden, act_dim, obs, w1, w2, w3, w4, bias, act, 0.f, 0.f, 0, 0, 0, stream);
 }
 
 int asm_batch_check_lattice(const asm_params *prm, int E, const float *grid, const int32_t *n_g,

@@ -223,7 +223,8 @@ int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ri
 }
 
 int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1, const void *w2,
-                      const void *w3, const void *w4, const float *bias, float *act, hipStream_t st)
+                      const void *w3, const void *w4, const float *bias, float *act, float noise_scale, float epsilon,
+                      uint64_t seed, uint32_t step, int64_t env0, hipStream_t st)
 {
     const int TPE = (n_a + 31) / 32, ntiles = E * TPE, K1 = (obs_dim + 15) / 16;
     const dim3 grid((unsigned)((ntiles + 7) / 8)), block(256);
@@ -235,7 +236,7 @@ int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, cons
     auto go = [&](auto kernel) {
         if (int rc = set_lds(kernel, lds)) return rc;
         hipLaunchKernelGGL(kernel, grid, block, lds, st, n_a, obs_dim, K1, act_dim, TPE, ntiles, half_frags, obs, (const uint4 *)w1,
-                           (const uint4 *)w2, (const uint4 *)w3, (const uint4 *)w4, bias, act);
+                           (const uint4 *)w2, (const uint4 *)w3, (const uint4 *)w4, bias, act, noise_scale, epsilon, seed, step, env0);
         LAUNCH_CHECK();
         return 0;
     };

@@ -39,7 +39,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int HT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_frags, const float *obs_g, const uint4 *w1,
-                  const uint4 *w2, const uint4 *w3, const uint4 *w4, const float *bias, float *out_g)
+                  const uint4 *w2, const uint4 *w3, const uint4 *w4, const float *bias, float *out_g, float noise_scale,
+                  float epsilon, uint64_t seed, uint32_t step, int64_t env0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 32 * HT, KS = 2 * HT, KH = HT, PF = 4;           // KH: k-steps per half of a hidden layer
@@ -195,12 +196,43 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[0][s], o[0], 0, 0, 0);
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[1][s], o[1], 0, 0, 0);
     }
+    // Exploration (agents.py:86-94), when asked for: per environment one coin -- with probability epsilon the whole team
+    // acts uniformly at random, else Gaussian noise is added and the action clamped to [-1, 1].  Counter-based draws
+    // (Philox4x32-10, stream 3) keyed by the GLOBAL environment id, the agent, the output pair and the caller's step
+    // counter: the same numbers whatever the batch is split into.
+    const bool explore = noise_scale > 0.f || epsilon > 0.f;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (ok[u] && row < A)
-                out_g[((size_t)env[u] * A + row) * n_a + agent[u]] = tanhf(o[u][q] + bl[3 * H + row]);
+    for (int u = 0; u < 2; ++u) {
+        const uint64_t eg = (uint64_t)(env0 + env[u]);
+        const uint32_t k0 = (uint32_t)eg, k1 = (uint32_t)seed ^ (uint32_t)(eg >> 32) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u;
+        bool all_uniform = false;
+        if (explore && epsilon > 0.f) {
+            uint32_t c4[4];
+            philox4x32(0xFFFFFFFFu, step, 3u, 0u, k0, k1, c4);
+            all_uniform = (float)c4[0] * (1.0f / 4294967296.0f) < epsilon;         // agents.py:87
         }
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {                               // registers q, q + 1 are rows row, row + 1
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            if (!ok[u] || row >= A) continue;
+            float a0 = tanhf(o[u][q] + bl[3 * H + row]), a1 = tanhf(o[u][q + 1] + bl[3 * H + row + 1]);
+            if (explore) {
+                uint32_t d[4];
+                philox4x32((uint32_t)agent[u] * 16u + (uint32_t)(row >> 1), step, 3u, 1u, k0, k1, d);
+                if (all_uniform) {                                     // agents.py:88
+                    a0 = -1.f + 2.f * ((float)d[2] * (1.0f / 4294967296.0f));
+                    a1 = -1.f + 2.f * ((float)d[3] * (1.0f / 4294967296.0f));
+                } else {                                               // agents.py:91-94, Box-Muller on two of the draws
+                    const float u1 = ((float)(d[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(d[1] >> 8) * (1.0f / 16777216.0f);
+                    const float rad = __builtin_sqrtf(-2.0f * __logf(u1)) * noise_scale;
+                    float sn, cs;
+                    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+                    a0 = __builtin_fminf(__builtin_fmaxf(a0 + rad * cs, -1.f), 1.f);
+                    a1 = __builtin_fminf(__builtin_fmaxf(a1 + rad * sn, -1.f), 1.f);
+                }
+            }
+            out_g[((size_t)env[u] * A + row) * n_a + agent[u]] = a0;
+            if (row + 1 < A) out_g[((size_t)env[u] * A + row + 1) * n_a + agent[u]] = a1;
+        }
+    }
 }

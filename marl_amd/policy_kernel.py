@@ -57,15 +57,19 @@ class FusedPolicyBF16:
         b4[:self.act_dim] = p.fc4.bias.detach().float()
         self.bias = torch.cat([p.fc1.bias.detach().float(), p.fc2.bias.detach().float(), p.fc3.bias.detach().float(), b4]).contiguous()
 
-    def forward(self, obs: torch.Tensor, out: torch.Tensor, stream: int = None) -> torch.Tensor:
+    def forward(self, obs: torch.Tensor, out: torch.Tensor, stream: int = None, noise_scale: float = 0.0, epsilon: float = 0.0,
+                seed: int = 0, step: int = 0, env0: int = 0) -> torch.Tensor:
+        """out = policy(obs); with noise_scale / epsilon > 0 the exploration of agents.py:86-94 is applied in the kernel
+        (counter-based draws keyed by seed, global environment id env0 + e, agent and `step`: advance step per call)."""
         E, d, n = obs.shape
         if d != self.obs_dim or out.shape != (E, self.act_dim, n) or obs.dtype != torch.float32 or out.dtype != torch.float32 \
                 or not obs.is_contiguous() or not out.is_contiguous() or obs.device.type != "cuda":
             raise ValueError("obs must be a contiguous float32 (E, obs_dim, n_a) device tensor and out (E, act_dim, n_a)")
         if stream is None:
             stream = torch.cuda.current_stream(obs.device).cuda_stream
-        _lib.check(self.lib.asm_policy_mlp_forward_bf16(E, n, d, self.hidden, self.act_dim, obs.data_ptr(), self.w1.data_ptr(),
-                                                        self.w2.data_ptr(), self.w3.data_ptr(), self.w4.data_ptr(),
-                                                        self.bias.data_ptr(), out.data_ptr(), stream),
-                   "asm_policy_mlp_forward_bf16")
+        _lib.check(self.lib.asm_policy_mlp_act_bf16(E, n, d, self.hidden, self.act_dim, obs.data_ptr(), self.w1.data_ptr(),
+                                                    self.w2.data_ptr(), self.w3.data_ptr(), self.w4.data_ptr(),
+                                                    self.bias.data_ptr(), out.data_ptr(), float(noise_scale), float(epsilon),
+                                                    int(seed) & (2 ** 64 - 1), int(step) & 0xFFFFFFFF, int(env0), stream),
+                   "asm_policy_mlp_act_bf16")
         return out

@@ -69,7 +69,7 @@ class DDPGLearner:
 
     def __init__(self, obs_dim: int, act_dim: int = 2, hidden_dim: int = 256, lr_actor: float = 1e-4,
                  lr_critic: float = 1e-3, gamma: float = 0.95, tau: float = 0.01, device="cuda", act_dtype=None,
-                 data_parallel: bool = False, group=None, capturable: bool = False):
+                 data_parallel: bool = False, group=None, capturable: bool = False, explore_seed: int = 0):
         mk = lambda i, o, c: MLPNetwork(i, o, hidden_dim, c).to(device)
         self.policy, self.target_policy = mk(obs_dim, act_dim, True), mk(obs_dim, act_dim, True)
         self.critic, self.target_critic = mk(obs_dim + act_dim, 1, False), mk(obs_dim + act_dim, 1, False)
@@ -99,20 +99,28 @@ class DDPGLearner:
         # bf16 rollouts on a HIP device go through the library's matrix-core kernel (marl_amd/policy_kernel.py) when the
         # network has a shape it takes; the weights are re-packed after every update
         self.fused_policy, self._policy_version, self._packed_version = None, 0, 0
+        self.explore_seed, self._explore_step = int(explore_seed), 0      # the kernel's exploration draws: (seed, call counter)
         if act_dtype is torch.bfloat16 and torch.device(device).type == "cuda" and hidden_dim in (32, 64, 128, 256) and act_dim <= 32:
             from .policy_kernel import FusedPolicyBF16
             self.fused_policy = FusedPolicyBF16(self.policy)
 
     @torch.no_grad()
     def act(self, obs: torch.Tensor, out: torch.Tensor, noise_scale: float = 0.0, epsilon: float = 0.0,
-            generator: Optional[torch.Generator] = None) -> torch.Tensor:
+            generator: Optional[torch.Generator] = None, env0: int = 0) -> torch.Tensor:
         """agents.py:69-96 for a batch of environments: obs (E, obs_dim, n_a) -> out (E, 2, n_a).
         Per environment (the reference draws its coin once per step of its one environment, agents.py:87):
         with probability epsilon the whole team acts uniformly at random, else Gaussian noise is added and the
-        action clamped to [-1, 1].  generator: a torch.Generator on the environment's device."""
+        action clamped to [-1, 1].  generator: a torch.Generator on the environment's device; without one, the
+        matrix-core policy kernel (bf16 rollouts) draws the exploration itself, keyed by explore_seed, the global
+        environment id env0 + e and a call counter, and writes the final actions in one launch."""
         E, d, n = obs.shape
-        if self.fused_policy is not None and obs.is_contiguous() and out.is_contiguous() and noise_scale <= 0.0 and epsilon <= 0.0:
-            return self._fused(obs, out)                                   # no exploration: the kernel writes the actions in place
+        if self.fused_policy is not None and obs.is_contiguous() and out.is_contiguous() and \
+                (generator is None or (noise_scale <= 0.0 and epsilon <= 0.0)):
+            if self._packed_version != self._policy_version:
+                self.fused_policy.repack(); self._packed_version = self._policy_version
+            self._explore_step += 1
+            return self.fused_policy.forward(obs, out, noise_scale=max(noise_scale, 0.0), epsilon=max(epsilon, 0.0),
+                                             seed=self.explore_seed, step=self._explore_step, env0=env0)
         if self.fused_policy is not None and obs.is_contiguous():
             a = self._fused(obs, torch.empty_like(out)).transpose(1, 2)    # (E, n, act_dim), as below
         else:
@@ -195,7 +203,7 @@ def run_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
     obs = env.reset()
     for _ in range(episode_length):
         a = replay.action_slot()
-        learner.act(obs, a, noise_scale, epsilon, generator)
+        learner.act(obs, a, noise_scale, epsilon, generator, env0=env.env_id_offset)
         obs = env.step(a)[0]
         replay.advance()
     return reduce_episode_stats(env.episode_stats())

@@ -61,9 +61,19 @@ def test_learner_uses_the_kernel_for_bf16_rollouts(torch_cuda):
     assert learner.fused_policy is not None
     a = torch.empty(64, 2, 30, device="cuda"); b = torch.empty_like(a)
     learner.act(obs, a)
-    learner.fused_policy = None                                       # PyTorch autocast path
+    keep, learner.fused_policy = learner.fused_policy, None           # PyTorch autocast path
     learner.act(obs, b)
     assert float((a - b).abs().max()) < 3e-2
+    learner.fused_policy = keep
+    learner.act(obs, b, noise_scale=0.5, epsilon=0.1)                 # exploration drawn by the kernel: a new draw per call
+    c = torch.empty_like(b)
+    learner.act(obs, c, noise_scale=0.5, epsilon=0.1)
+    assert not torch.equal(b, c) and float(b.abs().max()) <= 1.0
+    g = torch.Generator(device="cuda").manual_seed(1)                 # with a generator: the torch draws (seedable by the caller)
+    learner.act(obs, b, noise_scale=0.5, epsilon=0.1, generator=g)
+    g.manual_seed(1)
+    learner.act(obs, c, noise_scale=0.5, epsilon=0.1, generator=g)
+    assert torch.equal(b, c)
     # after an update the packed weights follow the network
     learner = DDPGLearner(env.obs_dim_agent, device="cuda", act_dtype=torch.bfloat16)
     learner.act(obs, a)
@@ -74,3 +84,50 @@ def test_learner_uses_the_kernel_for_bf16_rollouts(torch_cuda):
     with torch.no_grad():
         full = learner.policy(obs.transpose(1, 2).reshape(-1, env.obs_dim_agent)).view(64, 30, 2).transpose(1, 2)
     assert float((b - full).abs().max()) < 3e-2 and float((a - b).abs().max()) > 0
+
+
+def test_policy_kernel_exploration(torch_cuda):
+    """agents.py:86-94 in the kernel's epilogue: the epsilon coin is per environment, uniform actions fill [-1, 1), the
+    noise is N(0, scale^2) and clamped, draws depend on (seed, step, global environment id) only."""
+    torch = torch_cuda
+    from marl_amd.rollout import MLPNetwork
+    from marl_amd.policy_kernel import FusedPolicyBF16
+    torch.manual_seed(3)
+    E, n_a, d = 4096, 30, 192
+    net = MLPNetwork(d, 2, 256, constrain_out=True).cuda()
+    with torch.no_grad():
+        net.fc4.weight.mul_(0.2)                                      # actions well inside (-1, 1)
+    fused = FusedPolicyBF16(net)
+    obs = torch.randn(E, d, n_a, device="cuda") * 0.5
+    det = torch.empty(E, 2, n_a, device="cuda"); a = torch.empty_like(det); b = torch.empty_like(det)
+    fused.forward(obs, det)
+    # everybody uniform
+    fused.forward(obs, a, epsilon=1.0, seed=5, step=1)
+    assert float(a.min()) >= -1.0 and float(a.max()) < 1.0
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.var()) - 1.0 / 3.0) < 5e-3
+    # Gaussian noise, clamped
+    fused.forward(obs, a, noise_scale=0.3, seed=5, step=2)
+    z = (a - det) / 0.3
+    inside = a.abs() < 1.0
+    assert float(inside.float().mean()) > 0.95 and float(a.abs().max()) <= 1.0
+    assert abs(float(z[inside].mean())) < 5e-3 and abs(float(z[inside].std()) - 1.0) < 2e-2
+    assert abs(float((z[inside] ** 4).mean()) - 3.0) < 0.15            # a Gaussian's fourth moment (mild truncation by the clamp)
+    zz = z.view(E, 2, n_a)
+    assert abs(float((zz[:, 0] * zz[:, 1]).mean())) < 5e-3             # the two outputs of an agent are independent
+    # the coin is per environment
+    fused.forward(obs, a, epsilon=0.25, seed=5, step=3)
+    same = (a == det).view(E, -1)
+    per_env = same.all(dim=1)
+    assert bool((per_env | ~same.any(dim=1)).all())                    # an environment is either untouched or all random
+    assert abs(float((~per_env).float().mean()) - 0.25) < 0.03
+    # draws: functions of (seed, step, global environment id)
+    fused.forward(obs, b, epsilon=0.25, seed=5, step=3)
+    assert torch.equal(a, b)
+    fused.forward(obs, b, epsilon=0.25, seed=5, step=4)
+    assert not torch.equal(a, b)
+    fused.forward(obs, b, epsilon=0.25, seed=6, step=3)
+    assert not torch.equal(a, b)
+    fused.forward(obs, a, noise_scale=0.3, epsilon=0.1, seed=9, step=7)
+    half = torch.empty(E // 2, 2, n_a, device="cuda")
+    fused.forward(obs[E // 2:].contiguous(), half, noise_scale=0.3, epsilon=0.1, seed=9, step=7, env0=E // 2)
+    assert torch.equal(half, a[E // 2:])
