@@ -159,7 +159,7 @@ def test_bench_roofline_inputs():
         assert line["value"] == pytest.approx(c["global_envs"] * c["agents"] / (line["ms_per_step"] * 1e-3))
         assert line["timing"]["windows"] >= 5 and line["timing"]["steps_per_window"] == line["steps"]
         assert f'{c["agents"]}-agent' in line["metric"]
-    # a 20-step run measures the same step time as the 2000-step run (both on one box, round 2)
+    # a 20-step run measures the same step time as the 2000-step run (both taken on one box, one after the other)
     assert lines[1]["ms_per_step"] == pytest.approx(lines[0]["ms_per_step"], rel=0.03)
     assert lines[0]["cpu_baseline"]["kind"] in ("reference", "port") and lines[0]["cpu_baseline"]["cores"] >= 1
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash tools/profile_r02.sh
-# Everything the round-2 profiles/ files come from: bench lines, rocprofv3 kernel traces and counter passes for the
+# Everything the profiles/r02_* files come from: bench lines, rocprofv3 kernel traces and counter passes for the
 # 4096 x 30 benchmark and for 256 x 1024 (config 4).  Every GPU step has its own time limit; the script stops at
 # the first failure.
 set -e
