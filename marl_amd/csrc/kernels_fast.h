@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(0);
 #ifdef ASM_DIAG
     if (g_diag && l == 0) g_diag[(size_t)blockIdx.x * 32 + 20 + sub] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID of this wave
+    if (g_diag && tid == 0) g_diag[(size_t)blockIdx.x * 32 + 24] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // XCC_ID
 #endif
 
 #ifdef ASM_EXITS

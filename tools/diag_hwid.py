@@ -23,3 +23,12 @@ for s in range(4):
     print(f"wave {s}: SIMD histogram {np.bincount(simd[:, s], minlength=4).tolist()}  wave-slot histogram {np.bincount(wave[:, s], minlength=16).tolist()}")
 print("workgroups whose 4 waves sit on 4 different SIMDs:", int((np.sort(simd, axis=1) == np.arange(4)).all(axis=1).sum()))
 print("first 6 workgroups (simd of waves 0..3):", simd[:6].tolist())
+# per CU: do the first waves (the heaviest role) of the workgroups resident together sit on different SIMDs?
+xcc = b[:, 24] & 15
+se = (hw[:, 0] >> 13) & 7; sh = (hw[:, 0] >> 12) & 1
+key = ((xcc * 8 + se) * 2 + sh) * 16 + cu[:, 0]
+dist = {}
+for k in np.unique(key):
+    s0 = np.sort(simd[key == k, 0]).tolist()
+    dist[tuple(s0)] = dist.get(tuple(s0), 0) + 1
+print("CUs seen:", len(np.unique(key)), "; SIMDs of the first waves of a CU's workgroups -> number of CUs:", sorted(dist.items(), key=lambda kv: -kv[1])[:8])
