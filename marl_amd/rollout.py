@@ -98,7 +98,7 @@ class DDPGLearner:
         self.niter = 0
         # bf16 rollouts on a HIP device go through the library's matrix-core kernel (marl_amd/policy_kernel.py) when the
         # network has a shape it takes; the weights are re-packed after every update
-        self.fused_policy, self._policy_version, self._packed_version = None, 0, 0
+        self.fused_policy, self._policy_version, self._packed_version = None, 0, None
         self.explore_seed, self._explore_step = int(explore_seed), 0      # the kernel's exploration draws: (seed, call counter)
         if act_dtype is torch.bfloat16 and torch.device(device).type == "cuda" and hidden_dim in (32, 64, 128, 256) and act_dim <= 32:
             from .policy_kernel import FusedPolicyBF16
@@ -116,8 +116,7 @@ class DDPGLearner:
         E, d, n = obs.shape
         if self.fused_policy is not None and obs.is_contiguous() and out.is_contiguous() and \
                 (generator is None or (noise_scale <= 0.0 and epsilon <= 0.0)):
-            if self._packed_version != self._policy_version:
-                self.fused_policy.repack(); self._packed_version = self._policy_version
+            self._refresh_fused()
             self._explore_step += 1
             return self.fused_policy.forward(obs, out, noise_scale=max(noise_scale, 0.0), epsilon=max(epsilon, 0.0),
                                              seed=self.explore_seed, step=self._explore_step, env0=env0)
@@ -139,9 +138,19 @@ class DDPGLearner:
         out.copy_(a.transpose(1, 2))
         return out
 
+    def policy_changed(self) -> None:
+        """Tell the learner that the policy's weights were changed by something Python did not see run (a replayed HIP
+        graph); in-place changes made from Python (optimiser steps, load_state_dict) are noticed by themselves."""
+        self._policy_version += 1
+
+    def _refresh_fused(self) -> None:
+        # the packed bf16 copy follows the float32 weights: tensors count their in-place modifications (_version)
+        key = (self._policy_version, sum(p._version for p in self.policy.parameters()))
+        if key != self._packed_version:
+            self.fused_policy.repack(); self._packed_version = key
+
     def _fused(self, obs, out):
-        if self._packed_version != self._policy_version:
-            self.fused_policy.repack(); self._packed_version = self._policy_version
+        self._refresh_fused()
         return self.fused_policy.forward(obs, out)
 
     def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True,
@@ -180,7 +189,6 @@ class DDPGLearner:
         if self.data_parallel:
             self._pol_grads.average(self.group)                            # maddpg.py:179-180
         self.policy_optimizer.step()
-        self._policy_version += 1
         if sync_losses:
             return float(vf_loss.detach()), float(pol_loss.detach())
         return vf_loss.detach(), pol_loss.detach()
@@ -330,4 +338,5 @@ class GraphedTrainPhase:
             self.graph.replay()
             out[k].copy_(self.losses)
             self.learner.niter += 1
+        self.learner.policy_changed()                               # the replays moved the weights behind Python's back
         return out

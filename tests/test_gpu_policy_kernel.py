@@ -131,3 +131,36 @@ def test_policy_kernel_exploration(torch_cuda):
     half = torch.empty(E // 2, 2, n_a, device="cuda")
     fused.forward(obs[E // 2:].contiguous(), half, noise_scale=0.3, epsilon=0.1, seed=9, step=7, env0=E // 2)
     assert torch.equal(half, a[E // 2:])
+
+
+def test_fused_policy_follows_graphed_updates_and_loaded_weights(torch_cuda):
+    """The packed bf16 weights must follow the float32 network whoever changes it: an optimiser step from Python, a
+    train phase replayed from a HIP graph (Python sees nothing run), load_state_dict."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.replay import DeviceReplay
+    from marl_amd.rollout import DDPGLearner, GraphedTrainPhase, run_episode
+    env = BatchedAssemblyEnv(64, 30, seed=2)
+    rp = DeviceReplay(env, 8, 2, seed=0)
+    learner = DDPGLearner(env.obs_dim_agent, device="cuda", act_dtype=torch.bfloat16, capturable=True, hidden_dim=64)
+    run_episode(env, learner, rp, 8)
+    obs = env.reset()
+    a = torch.empty(64, 2, 30, device="cuda"); b = torch.empty_like(a)
+
+    def close_to_network():
+        learner.act(obs, b)
+        with torch.no_grad():
+            full = learner.policy(obs.transpose(1, 2).reshape(-1, env.obs_dim_agent)).view(64, 30, 2).transpose(1, 2)
+        return float((b - full).abs().max()) < 3e-2
+
+    learner.act(obs, a)
+    gt = GraphedTrainPhase(env, learner, rp, batch_size=256)
+    gt.run(num_updates=12)                                                # 3 warm-up updates from Python, 9 replays
+    assert close_to_network() and not torch.equal(a, b)
+    a.copy_(b)
+    gt.run(num_updates=10)                                                # replays only
+    assert close_to_network() and not torch.equal(a, b)
+    other = DDPGLearner(env.obs_dim_agent, device="cuda", hidden_dim=64)
+    learner.policy.load_state_dict(other.policy.state_dict())
+    a.copy_(b)
+    assert close_to_network() and not torch.equal(a, b)
