@@ -31,6 +31,17 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Two floats to a bf16 pair (round to nearest even), at this point of the program: written as a conversion of vector
+// elements the compiler forms the pair only where the operand is first used, a layer later, and keeps all 256
+// activated floats alive (and spilled) until then.
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 // (f32x2: kernels_common.h)
 
 // HT: hidden width / 32.  w1: [K1][HT][64] fragments (natural k order, K1 = ceil(obs_dim / 16)); w2, w3: [2 HT][HT][64],
@@ -61,6 +72,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         for (int f = wave; f < nfrag; f += 4)
             __builtin_amdgcn_global_load_lds(w + f * 64 + lane, (__attribute__((address_space(3))) void *)(dst + f * 64), 16, 0, 0);
     };
+    STAMP(0);
     dma(w1, K1 * HT, buf0);                                            // the whole first layer (it spans both buffers)
     for (int k = threadIdx.x; k < 3 * H + 32; k += 256) bl[k] = bias[k];
 
@@ -88,6 +100,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     constexpr int GM = HT >= 2 ? HT / 2 : 1, NG = HT / GM;
     bf16x8 Aq[2][GM];
     __syncthreads();                                                   // the first layer's weights and the biases are in LDS
+    STAMP(1);
 #pragma unroll
     for (int u = 0; u < 2; ++u)                                        // (cleared after the wait: nothing to keep alive across it)
 #pragma unroll
@@ -123,11 +136,12 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         }
     }
 #undef POLICY_FETCH
+    STAMP(2);
 
     // bias + leaky_relu (slope 0.01, F.leaky_relu's default: max(v, 0.01 v)) on the accumulators, packed as the next
     // layer's operands.  (Starting the sums from the bias instead, as the first MFMA's C operand, costs more registers
     // than the adds it saves: measured slower.)
-    bf16x8 F[2][KS];
+    u32x4 F[2][KS];                                                    // 8 bf16 per k-step and tile
     auto activate = [&](const float *b) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < HT; ++m)
@@ -135,13 +149,16 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b + 32 * m + 8 * g + 4 * h);    // rows 8g + 4h .. + 3
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int q = 4 * g + c;
-                        const float v = acc[u][m][q] + b4[c];
-                        F[u][2 * m + (q >> 3)][q & 7] = (__bf16)__builtin_fmaxf(v, 0.01f * v);
-                    }
+                for (int u = 0; u < 2; ++u) {
+                    // (bias add and the 0.01 product as packed pairs: v_pk_add_f32 / v_pk_mul_f32)
+                    const f32x2 ta = f32x2{acc[u][m][4 * g], acc[u][m][4 * g + 1]} + f32x2{b4[0], b4[1]};
+                    const f32x2 tb = f32x2{acc[u][m][4 * g + 2], acc[u][m][4 * g + 3]} + f32x2{b4[2], b4[3]};
+                    const f32x2 sa = ta * 0.01f, sb = tb * 0.01f;
+                    const float v[4] = {__builtin_fmaxf(ta.x, sa.x), __builtin_fmaxf(ta.y, sa.y), __builtin_fmaxf(tb.x, sb.x), __builtin_fmaxf(tb.y, sb.y)};
+                    // registers 4g .. 4g + 3 are elements (4g & 7) .. + 3 of k-step 2m + (g >> 1)
+                    F[u][2 * m + (g >> 1)][(g & 1) * 2] = pack_bf16x2(v[0], v[1]);
+                    F[u][2 * m + (g >> 1)][(g & 1) * 2 + 1] = pack_bf16x2(v[2], v[3]);
+                }
                 __builtin_amdgcn_sched_barrier(0);                     // (keeps the live temporaries of this pass few)
             }
     };
@@ -163,8 +180,8 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
 #pragma unroll
                 for (int m = 0; m < GM; ++m) {                          // the layer's first k-step starts the sums
                     const bool first = sa == 0 && t == 0;
-                    acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], F[0][sa + t], first ? zero : acc[0][g * GM + m], 0, 0, 0);
-                    acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], F[1][sa + t], first ? zero : acc[1][g * GM + m], 0, 0, 0);
+                    acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], __builtin_bit_cast(bf16x8, F[0][sa + t]), first ? zero : acc[0][g * GM + m], 0, 0, 0);
+                    acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], __builtin_bit_cast(bf16x8, F[1][sa + t]), first ? zero : acc[1][g * GM + m], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -172,20 +189,26 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     __syncthreads();                                                   // everybody is done with the first layer's weights
     dma(w2, KH * HT, buf0);
     activate(bl);
+    STAMP(3);
     __syncthreads();                                                   // w2's first half is in
     dma(w2 + (size_t)KH * HT * 64, KH * HT, buf1);
     hidden_part(buf0, 0);
+    STAMP(4);
     __syncthreads();                                                   // w2's second half is in; buf0 is free
     dma(w3, KH * HT, buf0);
     hidden_part(buf1, KH);
+    STAMP(5);
     activate(bl + H);
+    STAMP(6);
     __syncthreads();
     dma(w3 + (size_t)KH * HT * 64, KH * HT, buf1);
     hidden_part(buf0, 0);
     __syncthreads();
     dma(w4, KS, buf0);
     hidden_part(buf1, KH);
+    STAMP(7);
     activate(bl + 2 * H);
+    STAMP(8);
     __syncthreads();                                                   // the output layer's weights are in
 
     // ---- output layer (rows padded to one tile) and tanh ----
@@ -193,8 +216,8 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const bf16x8 Aw = __builtin_bit_cast(bf16x8, buf0[s * 64 + lane]);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[0][s], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, F[1][s], o[1], 0, 0, 0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, __builtin_bit_cast(bf16x8, F[0][s]), o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, __builtin_bit_cast(bf16x8, F[1][s]), o[1], 0, 0, 0);
     }
     // Exploration (agents.py:86-94), when asked for: per environment one coin -- with probability epsilon the whole team
     // acts uniformly at random, else Gaussian noise is added and the action clamped to [-1, 1].  Counter-based draws
@@ -235,4 +258,5 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
             if (row + 1 < A) out_g[((size_t)env[u] * A + row + 1) * n_a + agent[u]] = a1;
         }
     }
+    STAMP(9);
 }
