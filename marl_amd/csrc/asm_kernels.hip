@@ -45,8 +45,12 @@ __device__ unsigned long long *g_diag = nullptr;          // [grid][32]
 #define DIAG_COUNT(k, v) do { if (g_diag && threadIdx.x == 0) g_diag[(size_t)blockIdx.x * 32 + (k)] = (unsigned long long)(v); } while (0)
 #define STAMP(k) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
     if ((k) == 0) g_diag[(size_t)blockIdx.x * 32 + 10] = wall_clock64(); if ((k) == 9) g_diag[(size_t)blockIdx.x * 32 + 11] = wall_clock64(); } } while (0)
+// (the policy kernel's stamps: slots 0..29 in program order, wall clocks of the first and the last in slots 30 and 31)
+#define PSTAMP(k, last) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
+    if ((k) == 0) g_diag[(size_t)blockIdx.x * 32 + 30] = wall_clock64(); if (last) g_diag[(size_t)blockIdx.x * 32 + 31] = wall_clock64(); } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define PSTAMP(k, last) do { } while (0)
 #define DIAG_COUNT(k, v) do { } while (0)
 #endif
 

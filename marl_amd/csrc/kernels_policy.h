@@ -67,14 +67,22 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         env[u] = t / TPE; agent[u] = (t % TPE) * 32 + r;
         ok[u] = t0 + u < ntiles && agent[u] < n_a;
     }
-    // nfrag fragments from w into dst, every wave a quarter of them, all in flight at once
+    // nfrag fragments from w into dst, every wave a quarter of them, all in flight at once.  The copy instruction is
+    // written out (LDS destination = M0 + 16 bytes per lane): issued through the compiler's builtin it is accounted as an
+    // access that may return through either memory counter, and until the next full drain every wait for an LDS read
+    // becomes a wait for ALL LDS reads, the weight fragments just requested for the next MFMA group included.  The
+    // compiler therefore does not know of these copies: copies_landed() before the barrier that publishes them.  (M0 is
+    // a reserved register that the compiler sets immediately before each use of its own; nothing else here uses it.)
+    auto lds_addr = [](const void *p) __attribute__((always_inline)) {
+        return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+    };
     auto dma = [&](const uint4 *w, int nfrag, uint4 *dst) __attribute__((always_inline)) {
         for (int f = wave; f < nfrag; f += 4)
-            __builtin_amdgcn_global_load_lds(w + f * 64 + lane, (__attribute__((address_space(3))) void *)(dst + f * 64), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr(dst + f * 64))), "v"(w + f * 64 + lane) : "memory");
     };
-    STAMP(0);
-    dma(w1, K1 * HT, buf0);                                            // the whole first layer (it spans both buffers)
-    for (int k = threadIdx.x; k < 3 * H + 32; k += 256) bl[k] = bias[k];
+    auto copies_landed = []() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    PSTAMP(0, 0);
 
     // ---- layer 1: operands straight from the observation rows (8 consecutive features of one agent per lane) ----
     const float *col[2];
@@ -90,6 +98,13 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         }
 #pragma unroll
     for (int p = 0; p < PF; ++p) { POLICY_FETCH(p, p) }                 // (k-steps beyond K1 read nothing: k >= D)
+    // The first layer's weights (the whole layer: it spans both buffers) and the biases follow the observation rows
+    // into flight, all by the copy path: an ordinary load here would have to wait for every copy issued before it.
+    dma(w1, K1 * HT, buf0);
+    for (int k = wave * 64; k < 3 * H + 32; k += 256)
+        if (k + lane < 3 * H + 32)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr(bl + k))), "v"(bias + k + lane) : "memory");
 
     f32x16 acc[2][HT];
     f32x16 zero;
@@ -99,8 +114,9 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     // them (two register sets; 2 GM MFMAs = 64 GM cycles cover the read)
     constexpr int GM = HT >= 2 ? HT / 2 : 1, NG = HT / GM;
     bf16x8 Aq[2][GM];
+    copies_landed();
     __syncthreads();                                                   // the first layer's weights and the biases are in LDS
-    STAMP(1);
+    PSTAMP(1, 0);
 #pragma unroll
     for (int u = 0; u < 2; ++u)                                        // (cleared after the wait: nothing to keep alive across it)
 #pragma unroll
@@ -136,18 +152,25 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         }
     }
 #undef POLICY_FETCH
-    STAMP(2);
+    PSTAMP(2, 0);
 
     // bias + leaky_relu (slope 0.01, F.leaky_relu's default: max(v, 0.01 v)) on the accumulators, packed as the next
     // layer's operands.  (Starting the sums from the bias instead, as the first MFMA's C operand, costs more registers
     // than the adds it saves: measured slower.)
     u32x4 F[2][KS];                                                    // 8 bf16 per k-step and tile
     auto activate = [&](const float *b) __attribute__((always_inline)) {
+        // (the four biases of a register group are read one group ahead: a read waited for on the spot costs an LDS
+        // round trip per group, as much again as the group's arithmetic)
+        f32x4 bq[2];
+        bq[0] = *reinterpret_cast<const f32x4 *>(b + 4 * h);
 #pragma unroll
         for (int m = 0; m < HT; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b + 32 * m + 8 * g + 4 * h);    // rows 8g + 4h .. + 3
+                const int cur = g & 1, nx = (4 * m + g + 1 < 4 * HT) ? 4 * m + g + 1 : 4 * m + g;
+                bq[cur ^ 1] = *reinterpret_cast<const f32x4 *>(b + 8 * nx + 4 * h);                // rows 8g + 4h .. + 3 of tile m
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 b4 = bq[cur];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     // (bias add and the 0.01 product as packed pairs: v_pk_add_f32 / v_pk_mul_f32)
@@ -186,30 +209,43 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+    copies_landed();
     __syncthreads();                                                   // everybody is done with the first layer's weights
+    PSTAMP(3, 0);
     dma(w2, KH * HT, buf0);
     activate(bl);
-    STAMP(3);
+    PSTAMP(4, 0);
+    copies_landed();
     __syncthreads();                                                   // w2's first half is in
+    PSTAMP(5, 0);
     dma(w2 + (size_t)KH * HT * 64, KH * HT, buf1);
     hidden_part(buf0, 0);
-    STAMP(4);
+    PSTAMP(6, 0);
+    copies_landed();
     __syncthreads();                                                   // w2's second half is in; buf0 is free
+    PSTAMP(7, 0);
     dma(w3, KH * HT, buf0);
     hidden_part(buf1, KH);
-    STAMP(5);
+    PSTAMP(8, 0);
     activate(bl + H);
-    STAMP(6);
+    PSTAMP(9, 0);
+    copies_landed();
     __syncthreads();
+    PSTAMP(10, 0);
     dma(w3 + (size_t)KH * HT * 64, KH * HT, buf1);
     hidden_part(buf0, 0);
+    PSTAMP(11, 0);
+    copies_landed();
     __syncthreads();
+    PSTAMP(12, 0);
     dma(w4, KS, buf0);
     hidden_part(buf1, KH);
-    STAMP(7);
+    PSTAMP(13, 0);
     activate(bl + 2 * H);
-    STAMP(8);
+    PSTAMP(14, 0);
+    copies_landed();
     __syncthreads();                                                   // the output layer's weights are in
+    PSTAMP(15, 0);
 
     // ---- output layer (rows padded to one tile) and tanh ----
     f32x16 o[2] = {zero, zero};
@@ -219,6 +255,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, __builtin_bit_cast(bf16x8, F[0][s]), o[0], 0, 0, 0);
         o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aw, __builtin_bit_cast(bf16x8, F[1][s]), o[1], 0, 0, 0);
     }
+    PSTAMP(16, 0);
     // Exploration (agents.py:86-94), when asked for: per environment one coin -- with probability epsilon the whole team
     // acts uniformly at random, else Gaussian noise is added and the action clamped to [-1, 1].  Counter-based draws
     // (Philox4x32-10, stream 3) keyed by the GLOBAL environment id, the agent, the output pair and the caller's step
@@ -258,5 +295,5 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
             if (row + 1 < A) out_g[((size_t)env[u] * A + row + 1) * n_a + agent[u]] = a1;
         }
     }
-    STAMP(9);
+    PSTAMP(17, 1);
 }

@@ -32,13 +32,14 @@ for _ in range(10):
     buf.zero_()
     fused.forward(obs, out); torch.cuda.synchronize()
     b = buf.cpu().numpy()
-    acc.append(np.diff(b[:, :10], axis=1).astype(np.float64))
-    wall = (b[:, 11] - b[:, 10]) / 100.0
-    start = (b[:, 10] - b[:, 10].min()) / 100.0
+    acc.append(np.diff(b[:, :18], axis=1).astype(np.float64))
+    wall = (b[:, 31] - b[:, 30]) / 100.0
+    start = (b[:, 30] - b[:, 30].min()) / 100.0
 lib.asm_diag_set_buffer(None)
 d = np.mean(acc, axis=0)
-names = ["weights of layer 1 + first observation rows arrive", "layer 1 (12 k-steps, observation rows streamed)", "copy of w2a issued, activation 1",
-         "barrier, layer 2 first half", "barrier, layer 2 second half", "activation 2", "2 barriers, layer 3", "activation 3", "barrier, output layer, tanh, stores"]
+names = ["observation rows, w1, biases issued; barrier 1", "layer 1 (k-steps of 16 features, rows streamed)", "barrier 2", "copy w2a issued, activation 1",
+         "barrier 3", "layer 2 first half", "barrier 4", "layer 2 second half", "activation 2", "barrier 5", "layer 3 first half", "barrier 6",
+         "layer 3 second half", "activation 3", "barrier 7", "output layer", "tanh, exploration, stores"]
 print(f"workgroups {nwg}; lifetime us p50/max {np.percentile(wall, 50):.1f}/{wall.max():.1f}; start us p50/max {np.percentile(start, 50):.1f}/{start.max():.1f}; "
       f"cycles per workgroup {d.sum(1).mean():.0f}")
 for k, n in enumerate(names):
