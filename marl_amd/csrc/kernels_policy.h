@@ -57,7 +57,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     constexpr int H = 32 * HT, KS = 2 * HT, KH = HT, PF = 4;           // KH: k-steps per half of a hidden layer
     uint4 *const buf0 = reinterpret_cast<uint4 *>(smem), *const buf1 = buf0 + (size_t)half_frags * 64;
     float *const bl = reinterpret_cast<float *>(buf1 + (size_t)half_frags * 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
     const int t0 = (blockIdx.x * 4 + wave) * 2;
     int env[2], agent[2];
     bool ok[2];
@@ -76,10 +76,14 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     auto lds_addr = [](const void *p) __attribute__((always_inline)) {
         return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
     };
-    auto dma = [&](const uint4 *w, int nfrag, uint4 *dst) __attribute__((always_inline)) {
-        for (int f = wave; f < nfrag; f += 4)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr(dst + f * 64))), "v"(w + f * 64 + lane) : "memory");
+    // (LDS addresses as 32-bit integers off two scalar bases: a generic pointer per piece costs a 64-bit add, a null
+    // check and, unrolled, registers)
+    const unsigned a_buf0 = __builtin_amdgcn_readfirstlane(lds_addr(buf0)), a_buf1 = __builtin_amdgcn_readfirstlane(lds_addr(buf1));
+    auto dma_piece = [&](const uint4 *src, unsigned dst) __attribute__((always_inline)) {         // src per lane, dst per wave
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(src) : "memory");
+    };
+    auto dma = [&](const uint4 *w, int nfrag, unsigned dst) __attribute__((always_inline)) {
+        for (int f = wave; f < nfrag; f += 4) dma_piece(w + f * 64 + lane, dst + f * 1024);
     };
     auto copies_landed = []() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     PSTAMP(0, 0);
@@ -100,7 +104,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     for (int p = 0; p < PF; ++p) { POLICY_FETCH(p, p) }                 // (k-steps beyond K1 read nothing: k >= D)
     // The first layer's weights (the whole layer: it spans both buffers) and the biases follow the observation rows
     // into flight, all by the copy path: an ordinary load here would have to wait for every copy issued before it.
-    dma(w1, K1 * HT, buf0);
+    dma(w1, K1 * HT, a_buf0);
     for (int k = wave * 64; k < 3 * H + 32; k += 256)
         if (k + lane < 3 * H + 32)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
@@ -185,8 +189,12 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
                 __builtin_amdgcn_sched_barrier(0);                     // (keeps the live temporaries of this pass few)
             }
     };
-    // k-steps [sa, sa + KH) of a hidden layer from the fragments in wb
-    auto hidden_part = [&](const uint4 *wb, int sa) __attribute__((always_inline)) {
+    // k-steps [sa, sa + KH) of a hidden layer from the fragments in wb, after issuing the copy of the next block of
+    // weights (nfrag fragments from nw to ndst).  (The copies go out in one burst in front of the MFMAs: spread over
+    // the MFMA groups, a piece behind each group's first MFMAs, the same pieces cost more -- 30.4k cycles for the four
+    // halves against 27.8k.)
+    auto hidden_part = [&](const uint4 *wb, int sa, const uint4 *nw, int nfrag, unsigned ndst) __attribute__((always_inline)) {
+        dma(nw, nfrag, ndst);
 #pragma unroll
         for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, wb[m * 64 + lane]);
 #pragma unroll
@@ -212,34 +220,30 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     copies_landed();
     __syncthreads();                                                   // everybody is done with the first layer's weights
     PSTAMP(3, 0);
-    dma(w2, KH * HT, buf0);
+    dma(w2, KH * HT, a_buf0);
     activate(bl);
     PSTAMP(4, 0);
     copies_landed();
     __syncthreads();                                                   // w2's first half is in
     PSTAMP(5, 0);
-    dma(w2 + (size_t)KH * HT * 64, KH * HT, buf1);
-    hidden_part(buf0, 0);
+    hidden_part(buf0, 0, w2 + (size_t)KH * HT * 64, KH * HT, a_buf1);
     PSTAMP(6, 0);
     copies_landed();
     __syncthreads();                                                   // w2's second half is in; buf0 is free
     PSTAMP(7, 0);
-    dma(w3, KH * HT, buf0);
-    hidden_part(buf1, KH);
+    hidden_part(buf1, KH, w3, KH * HT, a_buf0);
     PSTAMP(8, 0);
     activate(bl + H);
     PSTAMP(9, 0);
     copies_landed();
     __syncthreads();
     PSTAMP(10, 0);
-    dma(w3 + (size_t)KH * HT * 64, KH * HT, buf1);
-    hidden_part(buf0, 0);
+    hidden_part(buf0, 0, w3 + (size_t)KH * HT * 64, KH * HT, a_buf1);
     PSTAMP(11, 0);
     copies_landed();
     __syncthreads();
     PSTAMP(12, 0);
-    dma(w4, KS, buf0);
-    hidden_part(buf1, KH);
+    hidden_part(buf1, KH, w4, KS, a_buf0);
     PSTAMP(13, 0);
     activate(bl + 2 * H);
     PSTAMP(14, 0);
@@ -260,39 +264,50 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     // acts uniformly at random, else Gaussian noise is added and the action clamped to [-1, 1].  Counter-based draws
     // (Philox4x32-10, stream 3) keyed by the GLOBAL environment id, the agent, the output pair and the caller's step
     // counter: the same numbers whatever the batch is split into.
+    // The code below is straight-line per register pair, for every lane, with only the stores predicated, and leaves at the
+    // first pair whose rows all lie beyond the action dimension: a branch around each unused pair is a taken branch to
+    // code not yet fetched, a dozen instruction-cache misses per workgroup.
     const bool explore = noise_scale > 0.f || epsilon > 0.f;
+    uint32_t k0[2], k1[2];
+    bool all_uniform[2] = {false, false};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint64_t eg = (uint64_t)(env0 + env[u]);
-        const uint32_t k0 = (uint32_t)eg, k1 = (uint32_t)seed ^ (uint32_t)(eg >> 32) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u;
-        bool all_uniform = false;
-        if (explore && epsilon > 0.f) {
-            uint32_t c4[4];
-            philox4x32(0xFFFFFFFFu, step, 3u, 0u, k0, k1, c4);
-            all_uniform = (float)c4[0] * (1.0f / 4294967296.0f) < epsilon;         // agents.py:87
-        }
+        k0[u] = (uint32_t)eg; k1[u] = (uint32_t)seed ^ (uint32_t)(eg >> 32) ^ (uint32_t)(seed >> 32) * 0x9E3779B9u;
+    }
+    if (explore && epsilon > 0.f) {
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {                               // registers q, q + 1 are rows row, row + 1
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (!ok[u] || row >= A) continue;
-            float a0 = tanhf(o[u][q] + bl[3 * H + row]), a1 = tanhf(o[u][q + 1] + bl[3 * H + row + 1]);
+        for (int u = 0; u < 2; ++u) {
+            uint32_t c4[4];
+            philox4x32(0xFFFFFFFFu, step, 3u, 0u, k0[u], k1[u], c4);
+            all_uniform[u] = (float)c4[0] * (1.0f / 4294967296.0f) < epsilon;      // agents.py:87
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {                                   // registers q, q + 1 are rows row, row + 1
+        if ((q & 3) + 8 * (q >> 2) >= A) break;                         // (the pairs' first rows increase with q)
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float b0 = bl[3 * H + row], b1 = bl[3 * H + row + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a0 = tanhf(o[u][q] + b0), a1 = tanhf(o[u][q + 1] + b1);
             if (explore) {
                 uint32_t d[4];
-                philox4x32((uint32_t)agent[u] * 16u + (uint32_t)(row >> 1), step, 3u, 1u, k0, k1, d);
-                if (all_uniform) {                                     // agents.py:88
-                    a0 = -1.f + 2.f * ((float)d[2] * (1.0f / 4294967296.0f));
-                    a1 = -1.f + 2.f * ((float)d[3] * (1.0f / 4294967296.0f));
-                } else {                                               // agents.py:91-94, Box-Muller on two of the draws
-                    const float u1 = ((float)(d[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(d[1] >> 8) * (1.0f / 16777216.0f);
-                    const float rad = __builtin_sqrtf(-2.0f * __logf(u1)) * noise_scale;
-                    float sn, cs;
-                    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
-                    a0 = __builtin_fminf(__builtin_fmaxf(a0 + rad * cs, -1.f), 1.f);
-                    a1 = __builtin_fminf(__builtin_fmaxf(a1 + rad * sn, -1.f), 1.f);
-                }
+                philox4x32((uint32_t)agent[u] * 16u + (uint32_t)(row >> 1), step, 3u, 1u, k0[u], k1[u], d);
+                // agents.py:88: the whole team uniformly at random
+                const float r0 = -1.f + 2.f * ((float)d[2] * (1.0f / 4294967296.0f)), r1 = -1.f + 2.f * ((float)d[3] * (1.0f / 4294967296.0f));
+                // agents.py:91-94, Box-Muller on two of the draws
+                const float u1 = ((float)(d[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(d[1] >> 8) * (1.0f / 16777216.0f);
+                const float rad = __builtin_sqrtf(-2.0f * __logf(u1)) * noise_scale;
+                float sn, cs;
+                __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+                const float g0 = __builtin_fminf(__builtin_fmaxf(a0 + rad * cs, -1.f), 1.f);
+                const float g1 = __builtin_fminf(__builtin_fmaxf(a1 + rad * sn, -1.f), 1.f);
+                a0 = all_uniform[u] ? r0 : g0;
+                a1 = all_uniform[u] ? r1 : g1;
             }
-            out_g[((size_t)env[u] * A + row) * n_a + agent[u]] = a0;
-            if (row + 1 < A) out_g[((size_t)env[u] * A + row + 1) * n_a + agent[u]] = a1;
+            if (ok[u] && row < A) out_g[((size_t)env[u] * A + row) * n_a + agent[u]] = a0;
+            if (ok[u] && row + 1 < A) out_g[((size_t)env[u] * A + row + 1) * n_a + agent[u]] = a1;
         }
     }
     PSTAMP(17, 1);
