@@ -235,8 +235,16 @@ int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, cons
     const int HT = hidden / 32;
     // two LDS buffers of this many 1 KiB fragments: half the first layer, half a hidden layer, the whole output layer
     const int half_frags = HT * std::max({(K1 + 1) / 2, HT, 2});
-    const size_t lds = (size_t)2048 * half_frags + 4 * (3 * (size_t)hidden + 32);
-    if (lds > 160 * 1024) return -1;
+    const size_t bias_bytes = 4 * (3 * (size_t)hidden + 32), lds_max = 160 * 1024;
+    size_t lds = bias_bytes + (size_t)2048 * half_frags;
+    if (lds > lds_max) return -1;
+    // Observation slabs through LDS where a k-step's 16 rows of an environment are one aligned contiguous block and at
+    // least two k-steps of slabs fit behind the first layer's weights.
+    const int ps = n_a > 16 ? 4 : 2;                                    // 1 KiB copy instructions per k-step and wave
+    const size_t lds_slabs = bias_bytes + (size_t)K1 * HT * 1024 + (size_t)4 * 3 * ps * 1024;
+    const bool slabs = TPE == 1 && HT >= 4 && ((size_t)obs_dim * n_a) % 4 == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 &&
+                       lds_slabs <= lds_max;
+    if (slabs) lds = std::max(lds, lds_slabs);
     auto go = [&](auto kernel) {
         if (int rc = set_lds(kernel, lds)) return rc;
         hipLaunchKernelGGL(kernel, grid, block, lds, st, n_a, obs_dim, K1, act_dim, TPE, ntiles, half_frags, obs, (const uint4 *)w1,
@@ -244,11 +252,15 @@ int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, cons
         LAUNCH_CHECK();
         return 0;
     };
-    switch (hidden) {
-    case 32: return go(k_policy_mlp<1>);
-    case 64: return go(k_policy_mlp<2>);
-    case 128: return go(k_policy_mlp<4>);
-    case 256: return go(k_policy_mlp<8>);
+    switch (hidden * 10 + (slabs ? ps : 0)) {
+    case 320: return go(k_policy_mlp<1, 0>);
+    case 640: return go(k_policy_mlp<2, 0>);
+    case 1280: return go(k_policy_mlp<4, 0>);
+    case 1282: return go(k_policy_mlp<4, 2>);
+    case 1284: return go(k_policy_mlp<4, 4>);
+    case 2560: return go(k_policy_mlp<8, 0>);
+    case 2562: return go(k_policy_mlp<8, 2>);
+    case 2564: return go(k_policy_mlp<8, 4>);
     default: return -1;
     }
 }

@@ -20,13 +20,20 @@
 // Weights reach the four waves of a workgroup through LDS, copied by global_load_lds_dwordx4 (LDS destination =
 // wave-uniform base + 16 bytes per lane, i.e. the packed layout itself; no registers): the whole first layer before
 // the first MFMA, the hidden layers half a layer at a time in two buffers, the copy of one half running under the
-// MFMAs of the other, one barrier per half.  (The first layer is not split: while such a copy is in flight the
-// compiler drains every outstanding load before any ordinary load's result is used, which would stall the observation
-// prefetch below.)  A wave alone on its SIMD cannot hide a weight fetch from memory per MFMA pair (the first version of
-// this kernel did that and ran at the speed of the PyTorch path), nor an LDS read per MFMA pair: the fragments of a
-// k-step are read one k-step ahead (two register sets, scheduling barriers keep the reads in front of the MFMAs they
-// overlap with).  The first layer's operands, 8 strided observation rows per lane and k-step, are fetched from memory
-// four k-steps ahead.
+// MFMAs of the other, one barrier per half.  A wave alone on its SIMD cannot hide a weight fetch from memory per MFMA
+// pair (the first version of this kernel did that and ran at the speed of the PyTorch path), nor an LDS read per MFMA
+// pair: the fragments of a k-step are read one group ahead (two register sets, scheduling barriers keep the reads in
+// front of the MFMAs they overlap with).
+//
+// The first layer's operands come from the observation rows.  Swarms of at most 32 agents (a tile = an environment)
+// with 16-byte aligned environments: a k-step's 16 rows are one contiguous slab, copied by the same instruction into
+// per-wave LDS slots three k-steps deep and read from there as 8 dwords per lane and tile (template parameter PS).
+// Otherwise 8 strided rows per lane and tile straight from memory into registers, four k-steps ahead.
+//
+// What bounds the phases of a workgroup (cycle stamps, hidden width 256, 192 features, 30 agents): layer 1 and the
+// prologue by the observation stream (every workgroup of the chip is in that phase at the same time); the hidden
+// layers by the matrix core plus the issue cost of the weight copies; the activations by their ~900 vector
+// instructions (256 accumulator reads, bias add and 0.01 product packed in pairs, 256 max, 128 packs).
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,8 +53,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 
 // HT: hidden width / 32.  w1: [K1][HT][64] fragments (natural k order, K1 = ceil(obs_dim / 16)); w2, w3: [2 HT][HT][64],
 // w4: [2 HT][1][64] (output rows padded to 32), all in the accumulator's k order; bias: [3 * 32 HT + 32] floats.
-// Dynamic LDS: two buffers of half_frags KiB, half_frags = HT x max(ceil(K1 / 2), HT, 2), then the biases.
-template <int HT>
+// Dynamic LDS: the biases, then two buffers of half_frags KiB, half_frags = HT x max(ceil(K1 / 2), HT, 2).
+// PS != 0 (swarms of at most 32 agents whose environments start on 16-byte boundaries; PS = 2 up to 16 agents, else 4):
+// the 16 observation rows of a k-step are one contiguous slab of 64 n_a bytes per environment, PS / 2 copy instructions
+// of 1 KiB; every wave copies the slabs of its two tiles into slots of its own behind the first layer's weights, three
+// k-steps deep, and reads its operands from there (LDS: the weights of layer 1, then 4 waves x 3 slots x PS KiB).
+template <int HT, int PS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_frags, const float *obs_g, const uint4 *w1,
                   const uint4 *w2, const uint4 *w3, const uint4 *w4, const float *bias, float *out_g, float noise_scale,
@@ -55,8 +66,8 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 32 * HT, KS = 2 * HT, KH = HT, PF = 4;           // KH: k-steps per half of a hidden layer
-    uint4 *const buf0 = reinterpret_cast<uint4 *>(smem), *const buf1 = buf0 + (size_t)half_frags * 64;
-    float *const bl = reinterpret_cast<float *>(buf1 + (size_t)half_frags * 64);
+    float *const bl = reinterpret_cast<float *>(smem);
+    uint4 *const buf0 = reinterpret_cast<uint4 *>(smem + 4 * (3 * H + 32)), *const buf1 = buf0 + (size_t)half_frags * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
     const int t0 = (blockIdx.x * 4 + wave) * 2;
     int env[2], agent[2];
@@ -85,30 +96,14 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     auto dma = [&](const uint4 *w, int nfrag, unsigned dst) __attribute__((always_inline)) {
         for (int f = wave; f < nfrag; f += 4) dma_piece(w + f * 64 + lane, dst + f * 1024);
     };
+    auto dma_bias = [&]() __attribute__((always_inline)) {
+        for (int k = wave * 64; k < 3 * H + 32; k += 256)
+            if (k + lane < 3 * H + 32)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                             :: "s"(__builtin_amdgcn_readfirstlane(lds_addr(bl + k))), "v"(bias + k + lane) : "memory");
+    };
     auto copies_landed = []() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     PSTAMP(0, 0);
-
-    // ---- layer 1: operands straight from the observation rows (8 consecutive features of one agent per lane) ----
-    const float *col[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) col[u] = obs_g + (size_t)env[u] * D * n_a + agent[u];
-    // xb[p]: the 16 observation values (2 tiles x 8 features) of a k-step, PF k-steps in flight
-    float xb[PF][16];
-#define POLICY_FETCH(S, P)                                                                            \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                       \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-            const int k = 16 * (S) + 8 * h + j;                                                         \
-            xb[P][u * 8 + j] = (ok[u] && k < D) ? col[u][(size_t)k * n_a] : 0.f;                        \
-        }
-#pragma unroll
-    for (int p = 0; p < PF; ++p) { POLICY_FETCH(p, p) }                 // (k-steps beyond K1 read nothing: k >= D)
-    // The first layer's weights (the whole layer: it spans both buffers) and the biases follow the observation rows
-    // into flight, all by the copy path: an ordinary load here would have to wait for every copy issued before it.
-    dma(w1, K1 * HT, a_buf0);
-    for (int k = wave * 64; k < 3 * H + 32; k += 256)
-        if (k + lane < 3 * H + 32)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
-                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr(bl + k))), "v"(bias + k + lane) : "memory");
 
     f32x16 acc[2][HT];
     f32x16 zero;
@@ -118,44 +113,182 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
     // them (two register sets; 2 GM MFMAs = 64 GM cycles cover the read)
     constexpr int GM = HT >= 2 ? HT / 2 : 1, NG = HT / GM;
     bf16x8 Aq[2][GM];
-    copies_landed();
-    __syncthreads();                                                   // the first layer's weights and the biases are in LDS
-    PSTAMP(1, 0);
+    // the MFMAs of k-step s of the first layer on the operands B, the fragments of the next group read ahead
+    auto layer1_step = [&](int s, int parity, const bf16x8 (&B)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)                                        // (cleared after the wait: nothing to keep alive across it)
+        for (int g = 0; g < NG; ++g) {
+            const int cur = (parity * NG + g) & 1;
+            const int nf = (g + 1 < NG) ? s * HT + (g + 1) * GM : (s + 1 < K1 ? (s + 1) * HT : s * HT);
 #pragma unroll
-        for (int m = 0; m < HT; ++m) acc[u][m] = zero;
+            for (int m = 0; m < GM; ++m) Aq[cur ^ 1][m] = __builtin_bit_cast(bf16x8, buf0[(nf + m) * 64 + lane]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, buf0[m * 64 + lane]);
-    for (int s0 = 0; s0 < K1; s0 += PF) {
+            for (int m = 0; m < GM; ++m) {
+                acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[0], acc[0][g * GM + m], 0, 0, 0);
+                acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[1], acc[1][g * GM + m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if constexpr (PS != 0) {
+        // ---- layer 1, operands through LDS slabs ----
+        // A k-step of this loop is bound by the number of instructions its one wave issues, not by the matrix core (16
+        // MFMAs are 512 cycles; 200 other instructions are twice that), so everything per k-step is pared down: slots at
+        // a fixed pitch of one or two copy instructions per tile (the lanes beyond the slab's end fetch its last piece
+        // again and land in the slot's padding; no lane is ever switched off), the copy's source as a scalar base plus
+        // a 32-bit lane offset, operand addresses that differ between the tiles by an immediate.  The rows of a short
+        // last slab beyond obs_dim keep what an earlier copy left in the slot -- observation values, finite -- and meet
+        // zero weights (the packed first layer is zero beyond obs_dim).
+        static_assert(NG % 2 == 0 && HT >= 4, "the fragment parity must carry over a k-step; eight chunks over HT MFMA pairs");
+        constexpr int PFD = 3, TILEB = PS == 4 ? 2048 : 1024, SLOTB = 2 * TILEB;
+        const int slab_bytes = 64 * n_a;                                // a full slab: 16 rows of n_a floats
+        const unsigned a_slab = a_buf0 + (unsigned)(K1 * HT) * 1024u + (unsigned)(wave * PFD * SLOTB);
+        const char *srcb[2];
 #pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            const int s = s0 + p;
-            if (s < K1) {
-                bf16x8 B[2];
+        for (int u = 0; u < 2; ++u) srcb[u] = reinterpret_cast<const char *>(obs_g + (size_t)env[u] * D * n_a);
+        unsigned soff = 0, loff[2] = {0, 0};                            // of the slab being issued: byte offset, lane offsets
+        auto slab_begin = [&](int q) __attribute__((always_inline)) {    // slab q, or the last one again beyond the end
+            const int qc = q < K1 ? q : K1 - 1;
+            const int rows = D - 16 * qc < 16 ? D - 16 * qc : 16;
+            const unsigned last16 = (unsigned)(rows * n_a / 4 - 1) * 16u;
+            soff = (unsigned)qc * (unsigned)slab_bytes;
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+            for (int p = 0; p < PS / 2; ++p) { const unsigned o = (unsigned)lane * 16u + 1024u * p; loff[p] = o < last16 ? o : last16; }
+        };
+        auto slab_piece = [&](int c, int slot) __attribute__((always_inline)) {       // copy instruction c of PS
+            const int u = PS == 4 ? c >> 1 : c, p = PS == 4 ? c & 1 : 0;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(a_slab + (unsigned)(slot * SLOTB + u * TILEB + p * 1024)), "v"(loff[p]), "s"(srcb[u] + soff) : "memory");
+        };
+        // this lane's 8 operand addresses in tile 0 of slot 0 (tile 1: + TILEB, slot n: + n SLOTB)
+        unsigned vrow[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) B[u][j] = (__bf16)xb[p][u * 8 + j];
-                POLICY_FETCH(s + PF, p)
+        for (int j = 0; j < 8; ++j) vrow[j] = a_slab + (unsigned)(((8 * h + j) * n_a + r) * 4);
+        typedef __attribute__((address_space(3))) const float lds_cf;
+        auto read_tile = [&](unsigned slot_off, int u, float (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const int cur = (p * NG + g) & 1;                  // (PF * NG is even: the parity carries over the outer loop)
-                    const int nf = (g + 1 < NG) ? s * HT + (g + 1) * GM : (s + 1 < K1 ? (s + 1) * HT : s * HT);
+            for (int j = 0; j < 8; ++j) x[j] = *(lds_cf *)(uintptr_t)(vrow[j] + slot_off + (unsigned)(u * TILEB));
+        };
+        auto pack_tile = [&](const float (&x)[8], u32x4 &B) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int m = 0; m < GM; ++m) Aq[cur ^ 1][m] = __builtin_bit_cast(bf16x8, buf0[(nf + m) * 64 + lane]);
+            for (int j = 0; j < 8; j += 2) B[j >> 1] = pack_bf16x2(x[j], x[j + 1]);
+        };
+        slab_begin(0);
+#pragma unroll
+        for (int c = 0; c < PS; ++c) slab_piece(c, 0);
+        dma(w1, K1 * HT, a_buf0);                                       // the whole first layer (it spans both buffers)
+        dma_bias();
+#pragma unroll
+        for (int q = 1; q < PFD; ++q) {
+            slab_begin(q);
+#pragma unroll
+            for (int c = 0; c < PS; ++c) slab_piece(c, q);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PFD - 1) * PS) : "memory");      // slab 0, the weights, the biases
+        __syncthreads();
+        PSTAMP(1, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < HT; ++m) acc[u][m] = zero;
+#pragma unroll
+        for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, buf0[m * 64 + lane]);
+        // The operands of k-step s + 1 are read and packed between the MFMAs of k-step s, from the slab that landed
+        // PFD - 1 k-steps after its issue; the slot of slab s, in registers since the k-step before, takes slab s + PFD.
+        // Eight chunks of that work (the copy instructions, wait + reads of tile 0, reads of tile 1, the two packs)
+        // follow the k-step's HT MFMA pairs, one or two a pair.
+        u32x4 Bn[2];
+        {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { read_tile(0, u, x); pack_tile(x, Bn[u]); }
+        }
+        int slot_wr = 0, slot_rd = 1;
+        for (int s = 0; s < K1; ++s) {
+            const bf16x8 B0 = __builtin_bit_cast(bf16x8, Bn[0]), B1 = __builtin_bit_cast(bf16x8, Bn[1]);
+            float xr[2][8];
+            auto chunk = [&](int c) __attribute__((always_inline)) {
+                if (c == 0) slab_begin(s + PFD);
+                if (c < PS) {
+                    slab_piece(c, slot_wr);
+                } else if (c == 4) {
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PFD - 1) * PS) : "memory");
+                    read_tile((unsigned)(slot_rd * SLOTB), 0, xr[0]);
+                } else if (c == 5) {
+                    read_tile((unsigned)(slot_rd * SLOTB), 1, xr[1]);
+                } else if (c == 6) {
+                    pack_tile(xr[0], Bn[0]);
+                } else if (c == 7) {
+                    pack_tile(xr[1], Bn[1]);
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cur = g & 1;
+                const int nf = (g + 1 < NG) ? s * HT + (g + 1) * GM : (s + 1 < K1 ? (s + 1) * HT : s * HT);
+#pragma unroll
+                for (int m = 0; m < GM; ++m) Aq[cur ^ 1][m] = __builtin_bit_cast(bf16x8, buf0[(nf + m) * 64 + lane]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < GM; ++m) {
+                    acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B0, acc[0][g * GM + m], 0, 0, 0);
+                    acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B1, acc[1][g * GM + m], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < GM; ++m) {
-                        acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[0], acc[0][g * GM + m], 0, 0, 0);
-                        acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], B[1], acc[1][g * GM + m], 0, 0, 0);
-                    }
+                    for (int c = (g * GM + m) * (8 / HT); c < (g * GM + m + 1) * (8 / HT); ++c) chunk(c);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            slot_wr = slot_rd;
+            slot_rd = slot_rd + 1 == PFD ? 0 : slot_rd + 1;
         }
-    }
+    } else {
+        // ---- layer 1: operands straight from the observation rows (8 consecutive features of one agent per lane) ----
+        const float *col[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) col[u] = obs_g + (size_t)env[u] * D * n_a + agent[u];
+        // xb[p]: the 16 observation values (2 tiles x 8 features) of a k-step, PF k-steps in flight
+        float xb[PF][16];
+#define POLICY_FETCH(S, P)                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                   \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+                const int k = 16 * (S) + 8 * h + j;                                                     \
+                xb[P][u * 8 + j] = (ok[u] && k < D) ? col[u][(size_t)k * n_a] : 0.f;                    \
+            }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) { POLICY_FETCH(p, p) }             // (k-steps beyond K1 read nothing: k >= D)
+        // The first layer's weights (the whole layer: it spans both buffers) and the biases follow the observation
+        // rows into flight, all by the copy path: an ordinary load here would have to wait for every copy issued
+        // before it.
+        dma(w1, K1 * HT, a_buf0);
+        dma_bias();
+        copies_landed();
+        __syncthreads();                                               // the first layer's weights and the biases are in LDS
+        PSTAMP(1, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)                                    // (cleared after the wait: nothing to keep alive across it)
+#pragma unroll
+            for (int m = 0; m < HT; ++m) acc[u][m] = zero;
+#pragma unroll
+        for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, buf0[m * 64 + lane]);
+        for (int s0 = 0; s0 < K1; s0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int s = s0 + p;
+                if (s < K1) {
+                    bf16x8 B[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) B[u][j] = (__bf16)xb[p][u * 8 + j];
+                    POLICY_FETCH(s + PF, p)
+                    layer1_step(s, p, B);                              // (PF * NG is even: the parity carries over the outer loop)
+                }
+            }
+        }
 #undef POLICY_FETCH
+    }
     PSTAMP(2, 0);
 
     // bias + leaky_relu (slope 0.01, F.leaky_relu's default: max(v, 0.01 v)) on the accumulators, packed as the next
@@ -189,12 +322,12 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
                 __builtin_amdgcn_sched_barrier(0);                     // (keeps the live temporaries of this pass few)
             }
     };
-    // k-steps [sa, sa + KH) of a hidden layer from the fragments in wb, after issuing the copy of the next block of
-    // weights (nfrag fragments from nw to ndst).  (The copies go out in one burst in front of the MFMAs: spread over
-    // the MFMA groups, a piece behind each group's first MFMAs, the same pieces cost more -- 30.4k cycles for the four
-    // halves against 27.8k.)
+    // k-steps [sa, sa + KH) of a hidden layer from the fragments in wb; the copy of the next block of weights (nfrag
+    // fragments from nw to ndst, a quarter per wave) is issued a piece per MFMA group, behind the group's second MFMA
+    // pair (scalar base + lane offset: two scalar adds and the copy, nothing for the vector ALU): 1 to 2 % faster than
+    // all pieces in one burst in front of the MFMAs.
+    const unsigned lane_piece = (unsigned)(wave * 1024 + lane * 16);
     auto hidden_part = [&](const uint4 *wb, int sa, const uint4 *nw, int nfrag, unsigned ndst) __attribute__((always_inline)) {
-        dma(nw, nfrag, ndst);
 #pragma unroll
         for (int m = 0; m < GM; ++m) Aq[0][m] = __builtin_bit_cast(bf16x8, wb[m * 64 + lane]);
 #pragma unroll
@@ -213,6 +346,15 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
                     const bool first = sa == 0 && t == 0;
                     acc[0][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], __builtin_bit_cast(bf16x8, F[0][sa + t]), first ? zero : acc[0][g * GM + m], 0, 0, 0);
                     acc[1][g * GM + m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[cur][m], __builtin_bit_cast(bf16x8, F[1][sa + t]), first ? zero : acc[1][g * GM + m], 0, 0, 0);
+                    if (m == (GM > 1 ? 1 : 0)) {
+                        const int i = t * NG + g;                       // piece i of this wave: fragment wave + 4 i
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (wave + 4 * i < nfrag)
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                                         :: "s"(ndst + (unsigned)(wave * 1024 + i * 4096)), "v"(lane_piece),
+                                            "s"(reinterpret_cast<const char *>(nw) + (size_t)i * 4096) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -17,8 +17,13 @@ def _reference_bf16(torch, net, x):
     return torch.tanh((h.double() @ r(net.fc4.weight).double().t() + net.fc4.bias.detach().double()).float())
 
 
+# The first layer takes its operands through LDS slabs where an environment's rows are one aligned block (at most 32
+# agents, obs_dim x n_a a multiple of 4, hidden width >= 128) and straight from memory otherwise: both kinds below, with
+# 1 or 2 copy instructions per slab (n_a <= 16 or more), 3 or 4 k-steps of slots (n_a = 32 leaves room for 3), obs_dim
+# not a multiple of 16 (a short last slab), fewer k-steps than slots, a rollout batch that ends inside a workgroup.
 @pytest.mark.parametrize("hidden,d,n_a,E,act", [(256, 192, 30, 70, 2), (64, 40, 7, 33, 2), (128, 192, 100, 5, 3), (32, 24, 32, 9, 1),
-                                                (256, 184, 1024, 2, 2)])
+                                                (256, 184, 1024, 2, 2), (256, 184, 32, 9, 2), (128, 200, 12, 21, 2),
+                                                (256, 24, 16, 5, 2), (128, 35, 28, 11, 4), (128, 33, 30, 3, 2)])
 def test_policy_kernel_matches_pytorch(torch_cuda, hidden, d, n_a, E, act):
     torch = torch_cuda
     from marl_amd.rollout import MLPNetwork
@@ -49,6 +54,12 @@ def test_policy_kernel_matches_pytorch(torch_cuda, hidden, d, n_a, E, act):
     with torch.no_grad():
         full = net(x).view(E, n_a, act).transpose(1, 2)
     assert float((out - full).abs().max()) < 3e-2                     # the price of bf16 operands
+    # 3. the same observations at an address that is not a multiple of 16 bytes (no slabs then): the same actions
+    shifted = torch.empty(obs.numel() + 1, device="cuda")[1:].view_as(obs)
+    shifted.copy_(obs)
+    out2 = torch.full_like(out, 7.0)
+    fused.forward(shifted, out2)
+    assert float((out2 - out).abs().max()) < 2e-3                     # (the two paths sum in the same order: normally 0)
 
 
 def test_learner_uses_the_kernel_for_bf16_rollouts(torch_cuda):
