@@ -106,20 +106,23 @@ class DDPGLearner:
 
     @torch.no_grad()
     def act(self, obs: torch.Tensor, out: torch.Tensor, noise_scale: float = 0.0, epsilon: float = 0.0,
-            generator: Optional[torch.Generator] = None, env0: int = 0) -> torch.Tensor:
+            generator: Optional[torch.Generator] = None, env0: int = 0, explore_step: Optional[int] = None) -> torch.Tensor:
         """agents.py:69-96 for a batch of environments: obs (E, obs_dim, n_a) -> out (E, 2, n_a).
         Per environment (the reference draws its coin once per step of its one environment, agents.py:87):
         with probability epsilon the whole team acts uniformly at random, else Gaussian noise is added and the
         action clamped to [-1, 1].  generator: a torch.Generator on the environment's device; without one, the
         matrix-core policy kernel (bf16 rollouts) draws the exploration itself, keyed by explore_seed, the global
-        environment id env0 + e and a call counter, and writes the final actions in one launch."""
+        environment id env0 + e and a call counter, and writes the final actions in one launch (explore_step: the
+        counter to use instead of the learner's own, for callers that act on several shards of one time step)."""
         E, d, n = obs.shape
         if self.fused_policy is not None and obs.is_contiguous() and out.is_contiguous() and \
                 (generator is None or (noise_scale <= 0.0 and epsilon <= 0.0)):
             self._refresh_fused()
-            self._explore_step += 1
+            if explore_step is None:
+                self._explore_step += 1
+                explore_step = self._explore_step
             return self.fused_policy.forward(obs, out, noise_scale=max(noise_scale, 0.0), epsilon=max(epsilon, 0.0),
-                                             seed=self.explore_seed, step=self._explore_step, env0=env0)
+                                             seed=self.explore_seed, step=explore_step, env0=env0)
         if self.fused_policy is not None and obs.is_contiguous():
             a = self._fused(obs, torch.empty_like(out)).transpose(1, 2)    # (E, n, act_dim), as below
         else:
@@ -207,6 +210,8 @@ def run_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
     """train_assembly.py:99-135 for E environments: reset, episode_length steps of act -> step, the
     environment writing straight into the replay slot.  Returns the episode statistics
     (mean reward, coverage, uniformity, contacts, distance to target — summarize() of the 8-vector)."""
+    if hasattr(env, "envs"):
+        return _run_episode_shards(env, learner, replay, episode_length, noise_scale, epsilon, generator)
     replay.begin_episode()
     obs = env.reset()
     for _ in range(episode_length):
@@ -215,6 +220,31 @@ def run_episode(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
         obs = env.step(a)[0]
         replay.advance()
     return reduce_episode_stats(env.episode_stats())
+
+
+def _run_episode_shards(shards, learner: DDPGLearner, replay: DeviceReplay, episode_length: int, noise_scale: float,
+                        epsilon: float, generator: Optional[torch.Generator]):
+    """run_episode for a StreamShards environment: every shard acts and steps on its own stream, so one shard's
+    policy launch runs beside the other's environment step and the ramps and tails of the launches overlap.  The
+    shards write their rows of the same replay frames; the kernel's exploration draws are keyed by global
+    environment id and time step, so the episode is the one a single environment of all E would have run."""
+    replay.begin_episode()
+    if learner.fused_policy is not None:
+        learner._refresh_fused()                                       # packed weights: now, on the current stream
+    cur = torch.cuda.current_stream(shards.device)
+    for s in shards.streams:
+        s.wait_stream(cur)                                             # the rollout follows whatever updated the weights
+    obs = shards.reset()
+    for _ in range(episode_length):
+        a = replay.action_slot()
+        learner._explore_step += 1
+        for k, (env, (first, count)) in enumerate(zip(shards.envs, shards.ranges)):
+            ak = a[first:first + count]
+            with torch.cuda.stream(shards.streams[k]):
+                learner.act(obs[k], ak, noise_scale, epsilon, generator, env0=env.env_id_offset, explore_step=learner._explore_step)
+            obs[k] = env.step(ak, shards._stream_ptrs[k])[0]
+        replay.advance()
+    return reduce_episode_stats(shards.episode_stats())                # (the current stream waits for the shards here)
 
 
 @torch.no_grad()

@@ -87,6 +87,33 @@ class StreamShards:
                 self.envs.append(BatchedAssemblyEnv(count, n_a, device=self.device, env_id_offset=env_id_offset + first, **env_kw))
             first += count
 
+    # ---- the shards seen as one environment of E (DeviceReplay, the train phase, run_episode) ----
+    @property
+    def ranges(self):
+        """(first environment, count) of every shard within this object's E environments."""
+        out, first = [], 0
+        for env in self.envs:
+            out.append((first, env.E)); first += env.E
+        return out
+
+    obs_dim_agent = property(lambda self: self.envs[0].obs_dim_agent)
+    training_method = property(lambda self: self.envs[0].training_method)
+    alpha = property(lambda self: self.envs[0].alpha)
+    env_id_offset = property(lambda self: self.envs[0].env_id_offset)
+
+    def _stream(self):
+        import ctypes as C
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _split(self, name: str, t: torch.Tensor) -> None:
+        for env, (a, n) in zip(self.envs, self.ranges):
+            setattr(env, name, t[a:a + n])                            # rows of environments: a contiguous block each
+
+    # Assigning an (E, ...) tensor points every shard's output at its rows of it (what DeviceReplay does per step).
+    obs = property(lambda self: [env.obs for env in self.envs], lambda self, t: self._split("obs", t))
+    reward = property(lambda self: [env.reward for env in self.envs], lambda self, t: self._split("reward", t))
+    a_prior = property(lambda self: [env.a_prior for env in self.envs], lambda self, t: self._split("a_prior", t))
+
     def on_each(self, fn, only: Optional[int] = None):
         """fn(k, env) for every shard (or shard `only`) with the shard's stream current; returns the list of results."""
         out = []

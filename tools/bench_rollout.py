@@ -33,6 +33,7 @@ ap.add_argument("--slots", type=int, default=2)
 ap.add_argument("--batch-size", type=int, default=2048)
 ap.add_argument("--graph", action="store_true", help="train phase as a replayed HIP graph (GraphedTrainPhase); single rank")
 ap.add_argument("--act-dtype", choices=["float32", "bfloat16"], default="float32", help="rollout inference precision")
+ap.add_argument("--shards", type=int, default=1, help="step the rank's environments as this many shards on streams of their own (StreamShards)")
 ap.add_argument("--no-fused", action="store_true", help="bf16 rollouts through PyTorch autocast instead of the library's matrix-core policy kernel")
 a = ap.parse_args()
 
@@ -53,7 +54,11 @@ if world > 1:
         dist.init_process_group(backend, rank=rank, world_size=world)
 
 torch.manual_seed(rank)
-env = BatchedAssemblyEnv(a.envs, a.agents, device=device, env_id_offset=shard_range(rank, world, a.envs)[0])
+if a.shards > 1:
+    from marl_amd.sharding import StreamShards
+    env = StreamShards(a.envs, a.agents, parts=a.shards, device=device, env_id_offset=shard_range(rank, world, a.envs)[0])
+else:
+    env = BatchedAssemblyEnv(a.envs, a.agents, device=device, env_id_offset=shard_range(rank, world, a.envs)[0])
 rp = DeviceReplay(env, a.episode_length, a.slots, seed=rank)
 learner = DDPGLearner(env.obs_dim_agent, device=device, act_dtype=torch.bfloat16 if a.act_dtype == "bfloat16" else None,
                       data_parallel=world > 1, capturable=a.graph)
@@ -93,6 +98,7 @@ if rank == 0:
                     f"policy/critic MLP 256, 30 updates of {a.batch_size} per episode and rank, replay in HBM "
                     f"({a.slots} episode slots), rollout inference in {a.act_dtype}"
                     + (" (fused matrix-core kernel)" if learner.fused_policy is not None else "")
+                    + (f", {a.shards} shards per GPU on streams of their own" if a.shards > 1 else "")
                     + (", learner replicas with averaged gradients" if world > 1 else "")
                     + (", train phase replayed from a HIP graph" if a.graph else ""),
         "n_gpus": world,
