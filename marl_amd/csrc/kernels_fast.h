@@ -75,6 +75,14 @@ __device__ __forceinline__ double half_max(double v)
     return v;
 }
 
+// stats[k] += v as one memory-side add without a returned value: the wave does not wait for the old value, so a
+// workgroup ends without a last round trip to memory.  Every statistic has exactly one adding lane per launch (launches
+// of a stream are ordered), so the sum is the same IEEE addition, in the same order, as a load / add / store.
+__device__ __forceinline__ void stat_add(double *p, double v)
+{
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+}
+
 // psi(z) of the reward's weighted mean (CPP:1017-1025 with delta = 0), the reference's expression
 __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 {
@@ -157,11 +165,22 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             lat_tv = reinterpret_cast<const uint4 *>(lat.shapes + (h ? sid1 : sid0))[tid - h * LAT_TAB_VEC];
         }
     };
+    // Everything the dynamics phase reads from memory is requested here, with the first round trip: the actions (first
+    // wave) and the prior's neighbour list, in-shape flag and nearest cell of the previous observation (second wave).
+    float act_x = 0.f, act_y = 0.f;
+    int nb_pre[6] = {-1, -1, -1, -1, -1, -1}, inf_pre = 0, near_pre = 0;
+    const bool prior_on = !P.observe_only && P.prior && prior_g;
     {
         float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
         if (sub == 0 && active) {
             const size_t o = (size_t)e * 2 * n_a;
             sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
+            if (!P.observe_only) { act_x = act_g[o + i]; act_y = act_g[o + n_a + i]; }
+        }
+        if (sub == SUB_PRIOR && active && prior_on) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+            if (!P.recompute) { inf_pre = inflag_g[(size_t)e * n_a + i]; near_pre = nearest_g[(size_t)e * n_a + i]; }
         }
         // The four coordinate rows (2 environments x {x, y}) are dealt out to the waves, so the row and its n_g are
         // wave-uniform and a lane's float4 index is just l, l + 64, ...; cells beyond n_g become far-away padding.
@@ -281,8 +300,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const double dfy = (-(c1 ? vy : 0.0) + -(c3 ? vy : 0.0)) * P.c_wall;
         // integration: ENV:626-647
         const float sens = (float)P.sens;
-        const double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);       // ENV:627,633
-        const double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        const double ux = (double)(sens * act_x);                                // ENV:627,633
+        const double uy = (double)(sens * act_y);
         const double Fx = PER ? ux + fx : ux + fx + wfx + dfx, Fy = PER ? uy + fy : uy + fy + wfy + dfy;   // ENV:633
         double ax = Fx, ay = Fy;
         if (P.mass != 1.0) { ax = Fx / P.mass; ay = Fy / P.mass; }               // ENV:638 (x / 1 == x)
@@ -298,17 +317,15 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         npx = (float)qx; npy = (float)qy;
         nvx = (float)v0; nvy = (float)v1;
     }
-    if (sub == SUB_PRIOR && active && P.prior && prior_g) {         // ENV:600-619: old state, previous neighbour list
+    if (sub == SUB_PRIOR && active && prior_on) {                   // ENV:600-619: old state, previous neighbour list
         const double px = L.px[l], py = L.py[l], vx = L.vx[l], vy = L.vy[l];
         int nb[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
-        bool inf; int near;
+        for (int q = 0; q < 6; ++q) nb[q] = nb_pre[q];
+        bool inf = inf_pre != 0; int near = near_pre;
         if (P.recompute) {
             double smin; cell_pass<float, false>(P, true, px, py, gxe, gye, l, nullptr, nullptr, nullptr, smin, near);
             inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
-        } else {
-            inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
         }
         const double tx = inf ? px : (double)gxe[near], ty = inf ? py : (double)gye[near];      // CPP:896-901
         double f0, f1;
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const double inn = (double)__popcll(__ballot(active && in_flag) & half);
             if (i == 0 && env_ok) {
                 double *st = stats_g + (size_t)e * 8;
-                st[0] += rs; st[1] += rq; st[7] += inn;
+                stat_add(&st[0], rs); stat_add(&st[1], rq); stat_add(&st[7], inn);
             }
         }
     }
@@ -1088,9 +1105,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         const double var = half_sum(dv * dv) / n_a;
         if (i == 0 && env_ok) {
             double *st = stats_g + (size_t)e * 8;
-            st[2] += n_g > 0 ? covered / n_g : 0.0;                   // WRAP:70; an environment without cells covers nothing
-            st[3] += (var - lo) / (hi - lo);                        // WRAP:98-99
-            st[4] += cp; st[5] += ds / n_a; st[6] += 1.0;
+            stat_add(&st[2], n_g > 0 ? covered / n_g : 0.0);          // WRAP:70; an environment without cells covers nothing
+            stat_add(&st[3], (var - lo) / (hi - lo));               // WRAP:98-99
+            stat_add(&st[4], cp); stat_add(&st[5], ds / n_a); stat_add(&st[6], 1.0);
         }
     }
     STAMP(9);
