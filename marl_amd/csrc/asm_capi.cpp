@@ -586,6 +586,8 @@ int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lat
 #ifdef ASM_DIAG
 // diagnostic build only: device buffer [grid][32] of cycle stamps, or NULL to stop stamping
 int asm_diag_set_buffer(void *dev) { return asmenv::diag_set_buffer((unsigned long long *)dev); }
+// k_step_fast stamps only the launches whose position array is p (NULL: every launch)
+int asm_diag_set_filter(const void *p) { return asmenv::diag_set_filter(p); }
 #endif
 
 int asm_debug_cos_f32_max_err(uint32_t bits_lo, uint32_t bits_hi, double *out_max, void *stream)

@@ -115,6 +115,7 @@ int launch_prior_compat(const DevParams &P, const double *p, const double *dp, c
 
 #ifdef ASM_DIAG
 int diag_set_buffer(unsigned long long *dev);
+int diag_set_filter(const void *p);
 #endif
 
 }  // namespace asmenv

@@ -42,6 +42,7 @@ __device__ int g_exit_at = 0;
 // of each workgroup's first wave to a buffer of its own.  The product build has no stamps.
 #ifdef ASM_DIAG
 __device__ unsigned long long *g_diag = nullptr;          // [grid][32]
+__device__ unsigned long long *g_diag_only = nullptr;           // k_step_fast: stamp only launches on this position array (NULL: all)
 #define DIAG_COUNT(k, v) do { if (g_diag && threadIdx.x == 0) g_diag[(size_t)blockIdx.x * 32 + (k)] = (unsigned long long)(v); } while (0)
 #define STAMP(k) do { if (g_diag && threadIdx.x == 0) { g_diag[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); \
     if ((k) == 0) g_diag[(size_t)blockIdx.x * 32 + 10] = wall_clock64(); if ((k) == 9) g_diag[(size_t)blockIdx.x * 32 + 11] = wall_clock64(); } } while (0)
@@ -269,6 +270,11 @@ int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, cons
 int diag_set_buffer(unsigned long long *dev)
 {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &dev, sizeof dev);
+}
+int diag_set_filter(const void *p)
+{
+    unsigned long long *q = (unsigned long long *)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_diag_only), &q, sizeof q);
 }
 #endif
 

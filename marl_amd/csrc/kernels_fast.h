@@ -91,6 +91,9 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
     return 0.0;
 }
 
+#ifndef ASM_OBS_AUX
+#define ASM_OBS_AUX 2        // cache policy of the observation stores: non-temporal (written once, read by a later kernel)
+#endif
 #ifndef ASM_W0_LESS
 #define ASM_W0_LESS 2        // words wave 0 gives up in the cell pass because it also runs the k-NN pass
 #endif
@@ -110,6 +113,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                                                       float *rew_g, float *prior_g, int *sensed_g, int *occup_g,
                                                       double *stats_g)
 {
+#ifdef ASM_DIAG
+    const unsigned long long dg_t0 = __builtin_readcyclecounter();   // the wave's first instruction
+    unsigned long long dg_t1 = 0, dg_t2 = 0, dg_b = 0, dg_c = 0;
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     // sub is the same for every lane of a wave: read through the scalar unit so that everything derived from
     // it (word and slot ranges, row offsets) stays in scalar registers
@@ -121,6 +128,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     float *gxe = L.g + (size_t)es * NGP, *gye = gxe + ASM_GY_OFF;
     unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
     constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
+#ifdef ASM_DIAG
+    unsigned long long *const g_diag_all = asmenv::g_diag;
+    unsigned long long *const g_diag = (g_diag_only && (const void *)g_diag_only != (const void *)p_g) ? nullptr : g_diag_all;   // shadows the global in this kernel
+#endif
     STAMP(0);
 #ifdef ASM_DIAG
     if (g_diag && l == 0) g_diag[(size_t)blockIdx.x * 32 + 20 + sub] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID of this wave
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int e0 = blockIdx.x * 2;
     const int ng0 = e0 < P.E ? clamp_ng(ng_g[e0], P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng_g[e0 + 1], P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
+#ifdef ASM_DIAG
+    asm volatile("" :: "s"(ng0));
+    const unsigned long long dg_a = __builtin_readcyclecounter();   // the first loaded value (n_g) is there
+#endif
     const double l_cell = env_ok ? lcell_g[e] : 1.0;
     // lattice path: the two environments' shape tables (row windows + boundary list, 1664 bytes each) go into the unused
     // part of the grid area, between the x rows and the y rows
@@ -155,6 +170,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         if (env_ok) { xf_c = lat.xform[(size_t)e * 4]; xf_s = lat.xform[(size_t)e * 4 + 1]; xf_ox = lat.xform[(size_t)e * 4 + 2]; xf_oy = lat.xform[(size_t)e * 4 + 3]; }
     }
     auto lat_loads = [&]() {
+#ifdef ASM_DIAG
+        dg_t1 = __builtin_readcyclecounter();                      // grid loads issued
+        asm volatile("" :: "s"(sid0));
+        dg_b = __builtin_readcyclecounter();                        // shape ids there
+#endif
         sid0 = sid0 < 0 ? 0 : (sid0 >= lat.n_shapes ? lat.n_shapes - 1 : sid0);
         sid1 = sid1 < 0 ? 0 : (sid1 >= lat.n_shapes ? lat.n_shapes - 1 : sid1);
         lat_nb0 = e0 < P.E ? lat.shapes[sid0].n_boundary : 0; lat_nb1 = e0 + 1 < P.E ? lat.shapes[sid1].n_boundary : 0;
@@ -198,6 +218,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                     if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
                 }
                 if constexpr (LAT) if (base == 0) lat_loads();      // T = 4: every wave passes here exactly once
+#ifdef ASM_DIAG
+                if (base == 0) { dg_c = __builtin_readcyclecounter(); asm volatile("" :: "v"(v[0].x)); dg_t2 = __builtin_readcyclecounter(); }
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = base + (q * 64 + l) * 4;
@@ -219,6 +242,13 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         if constexpr (LAT)
             for (int w = tid; w < 64 * MW; w += 64 * T) L.mask[w] = 0;   // the sensed masks are built by OR-ing runs of cells
     }
+#ifdef ASM_DIAG
+    if (g_diag && tid == 0) {                                       // first wave: its start, loads issued, first grid data there, arrival at the barrier
+        g_diag[(size_t)blockIdx.x * 32 + 25] = __builtin_readcyclecounter(); g_diag[(size_t)blockIdx.x * 32 + 26] = dg_t0;
+        g_diag[(size_t)blockIdx.x * 32 + 27] = dg_t1; g_diag[(size_t)blockIdx.x * 32 + 28] = dg_t2;
+        g_diag[(size_t)blockIdx.x * 32 + 19] = dg_a; g_diag[(size_t)blockIdx.x * 32 + 29] = dg_b; g_diag[(size_t)blockIdx.x * 32 + 30] = dg_c;
+    }
+#endif
     __syncthreads();
     STAMP(1);
     EXIT_AT(1);
@@ -361,7 +391,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e0 * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
     const int olb = (es * P.obs_dim * n_a + i) * 4;
     auto ostore = [&](int row, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, ASM_OBS_AUX);
     };
     double s6[6]; int j6[6];
 #pragma unroll

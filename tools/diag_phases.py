@@ -20,7 +20,7 @@ from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n_a = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 # third argument "2": a second batch of the same size is stepped on another stream all the time (the steady state of
-# the two-shard benchmark); its workgroups stamp into the same buffer, so the numbers are a mix of both launches
+# the two-shard benchmark); only the first batch's launches stamp
 other = None
 if len(sys.argv) > 3 and sys.argv[3] == "2":
     side = torch.cuda.Stream()
@@ -36,6 +36,7 @@ for t in range(30):
 grid = 8192
 buf = torch.zeros(grid, 32, dtype=torch.int64, device="cuda")
 assert lib.asm_diag_set_buffer(C.c_void_p(buf.data_ptr())) == 0
+rc = lib.asm_diag_set_filter(C.c_void_p(env.p.data_ptr())); assert rc == 0, rc    # the other batch's launches do not stamp
 acc = None
 for t in range(10):
     buf.zero_()
@@ -75,6 +76,10 @@ if b[:, 12].any():
         ll = (b[:, 6] - b[:, 16]).astype(np.float64)
         print("workgroups with a sub-sampling lane: %d of %d; list loop cycles %.0f with, %.0f without (%.1f iterations)" % (
             int(ss.sum()), b.shape[0], ll[ss].mean() if ss.any() else 0, ll[~ss].mean(), b[~ss, 17].mean()))
+if b[:, 25].any():
+    t = (b[:, [0, 19, 27, 29, 30, 28, 25, 1]] - b[:, [26]]).astype(np.float64).mean(0)
+    print("P0 of the first wave, cycles after its first instruction: first stamp %.0f | n_g there %.0f | grid loads issued %.0f | shape ids there %.0f | "
+          "table loads issued %.0f | first grid data %.0f | at the barrier %.0f | barrier released %.0f" % tuple(t))
 slow = np.argsort(-wall)[:5]
 print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
 names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
