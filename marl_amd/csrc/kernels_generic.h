@@ -388,6 +388,17 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             // weights in fp32 (v_cos_f32), decided in fp32 unless |v| is within the error bound of 0.05
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
             float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+            // The cell block's rows go out as buffer stores: resource = the observation block of the wave's first
+            // environment onwards, vector offset = the lane's column (plus its environment's distance from the first),
+            // scalar offset = the row, so a row store needs no vector address arithmetic; non-temporal, as the rows
+            // are written once and read by a later kernel.
+            const int e_first = __builtin_amdgcn_readfirstlane(e);
+            const __amdgpu_buffer_rsrc_t obs_rs =
+                __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e_first * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
+            const int olb = ((e - e_first) * P.obs_dim * n_a + i) * 4;
+            auto ostore = [&](int r, float v) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, r * n_a * 4, 2);
+            };
             auto slot = [&](int k, int cell) {
                 float gx = 0.f, gy = 0.f;
                 if (cell >= 0) {
@@ -398,7 +409,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                         fn0 = __builtin_fmaf(psi, gx, fn0); fn1 = __builtin_fmaf(psi, gy, fn1); fden += psi;
                     }
                 }
-                ocol[(size_t)(gb + 2 * k) * n_a] = (S)gx; ocol[(size_t)(gb + 2 * k + 1) * n_a] = (S)gy;
+                ostore(gb + 2 * k, gx); ostore(gb + 2 * k + 1, gy);
                 if (sdst) sdst[k] = cell;
             };
             if (P.W <= 32 && ((P.n_obs - 1) & 1)) {
