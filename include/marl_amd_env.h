@@ -204,7 +204,11 @@ int asm_batch_check_lattice(const asm_params *prm, int E, const float *grid, con
  *        [0] sum of rewards  [1] sum of squared rewards  [2] coverage_rate
  *        [3] distribution_uniformity  [4] contact pairs (pre-integration state)
  *        [5] average_distance_to_target  [6] 1 (step count)  [7] agents inside the shape
- *        (the per-step quantities TRAIN:128-135 accumulates; metrics of WRAP:48-165)
+ *        (the per-step quantities TRAIN:128-135 accumulates; metrics of WRAP:48-165).
+ *        The step kernel of swarms of at most 32 agents adds with memory-side double-precision
+ *        atomic adds that return nothing (one adding lane per entry and launch, so the sums are
+ *        those of a load / add / store): stats must lie in ordinary device memory (hipMalloc,
+ *        a torch CUDA tensor), not in host-pinned or fine-grained memory.
  */
 
 /*
