@@ -37,6 +37,7 @@ struct DevParams {
     int block, grid;
     unsigned lds_env_bytes, lds_block_bytes;
     int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
+    int obs_nt;                     // observation rows stored non-temporal (set per launch from the size of the observation array)
     unsigned fast_lds_bytes;
     int lat, lat_KO;                // lattice path: 0 off, 1 k_step_fast, 2 k_step (large swarms); lattice rows |k| <= lat_KO can hold an occupied cell
     float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)

@@ -110,8 +110,11 @@ static int launch_step_fast_t(const DevParams &P, const LatArgs &lat, float *p, 
         return 0;
     };
     if constexpr (T == 4)                                           // the lattice path exists for this schedule only
-        if (P.lat)
+        if (P.lat) {
+            if (P.obs_nt)
+                return occupied ? go(k_step_fast<T, PER, 2, true, true>) : sensed ? go(k_step_fast<T, PER, 1, true, true>) : go(k_step_fast<T, PER, 0, true, true>);
             return occupied ? go(k_step_fast<T, PER, 2, true>) : sensed ? go(k_step_fast<T, PER, 1, true>) : go(k_step_fast<T, PER, 0, true>);
+        }
     return occupied ? go(k_step_fast<T, PER, 2, false>) : sensed ? go(k_step_fast<T, PER, 1, false>) : go(k_step_fast<T, PER, 0, false>);
 }
 

@@ -91,9 +91,6 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
     return 0.0;
 }
 
-#ifndef ASM_OBS_AUX
-#define ASM_OBS_AUX 2        // cache policy of the observation stores: non-temporal (written once, read by a later kernel)
-#endif
 #ifndef ASM_W0_LESS
 #define ASM_W0_LESS 2        // words wave 0 gives up in the cell pass because it also runs the k-NN pass
 #endif
@@ -104,9 +101,12 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #define ASM_SPARSE_MAX 64    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent (64: always;
                              // measured as fast as the lane-by-lane loop even when every agent senses cells)
 #endif
-template <int T, bool PER, int IDX, bool LAT>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
+template <int T, bool PER, int IDX, bool LAT, bool NT = false>   // PER: periodic arena (no walls; wrapped neighbour offsets, ENV:97-101); IDX: index
                                       // lists written (0 none, 1 sensed_index if given, 2 occupied_index too); LAT: the agent x
-                                      // cell work runs on the shapes' lattice description (kernels_lattice.h; T = 4 only)
+                                      // cell work runs on the shapes' lattice description (kernels_lattice.h; T = 4 only);
+                                      // NT: the observation rows are stored non-temporal (launches whose observations are
+                                      // too large to stay in the last-level cache until a later kernel reads them: then
+                                      // they should not push the grids and the state out of it either)
 __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, LatArgs lat, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e0 * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
     const int olb = (es * P.obs_dim * n_a + i) * 4;
     auto ostore = [&](int row, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, ASM_OBS_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, NT ? 2 : 0);
     };
     double s6[6]; int j6[6];
 #pragma unroll
