@@ -240,12 +240,13 @@ def main():
     barrier()
     mark("environment reset, actions drawn")
     # The step time settles only after about 40 ms (1000 steps) of continuous load (clock ramp): when fewer warm-up
-    # steps are asked for, the difference is stepped first and the environments are put back to their episode-0 state.
-    if W < SETTLE_STEPS:
-        for t in range(SETTLE_STEPS - W):
-            shards.step([a[t % ring] for a in actions])
-        shards.on_each(lambda k, env: reset_one(k, env, 0))
-    run_steps(W)
+    # steps are asked for, the difference is stepped first, episode ends included, so that the timed region starts in
+    # the run's steady state whatever --warmup says: the shards' episodes staggered, each somewhere inside an episode
+    # (the first steps after a reset are the expensive ones -- half the environments start clustered -- and a timed
+    # region that began right after a reset of every shard would measure mostly those).
+    pre = max(SETTLE_STEPS - W, 0)
+    run_steps(pre)
+    run_steps(W, pre)
     mark("warm-up steps done")
     shards.on_each(lambda k, env: totals[k].add_(all_reduce_stats(env.episode_stats())))
     shards.synchronize()
@@ -257,20 +258,30 @@ def main():
     # barrier + synchronize.  Window boundaries are HIP events on every shard stream; a window's duration is the
     # longest of its per-stream intervals, and the reported step time is the MEDIAN window / K: the first window
     # absorbs the pipeline fill after the barrier and the last one the drain, whatever K is.
-    R = args.repeats if args.repeats > 0 else max(5, -(-400 // max(K, 1)))
+    # A window shorter than an episode sees only a part of the episode's cycle (every shard resets once per
+    # EPISODE_LENGTH steps, and the steps after a reset cost more): such windows are grouped into blocks of G windows
+    # that span a whole episode, and the step time is the median over the blocks (at least five).
+    G = 1 if K >= EPISODE_LENGTH else -(-EPISODE_LENGTH // max(K, 1))
+    R = args.repeats if args.repeats > 0 else G * max(5, -(-400 // max(G * K, 1)))
+    G = min(G, R)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(R + 1)] for _ in range(S)]
     t0 = time.perf_counter()
     for k in range(S):
         evs[k][0].record(shards.streams[k])
     for r in range(R):
-        run_steps(K, W + r * K)
+        run_steps(K, pre + W + r * K)
         for k in range(S):
             evs[k][r + 1].record(shards.streams[k])
     barrier()
     mark("timed region done")
     wall_all = time.perf_counter() - t0
-    win_ms = sorted(max(evs[k][r].elapsed_time(evs[k][r + 1]) for k in range(S)) for r in range(R))
-    med_ms = win_ms[R // 2] if R % 2 else 0.5 * (win_ms[R // 2 - 1] + win_ms[R // 2])
+    win_seq = [max(evs[k][r].elapsed_time(evs[k][r + 1]) for k in range(S)) for r in range(R)]
+    if os.environ.get("MARL_AMD_BENCH_WINDOWS") == "1" and rank == 0:
+        print("windows ms:", " ".join(f"{w:.3f}" for w in win_seq), file=sys.stderr)
+    win_ms = sorted(win_seq)
+    blocks = sorted(sum(win_seq[b * G:(b + 1) * G]) / G for b in range(R // G))      # ms per K steps, block by block
+    nb = len(blocks)
+    med_ms = blocks[nb // 2] if nb % 2 else 0.5 * (blocks[nb // 2 - 1] + blocks[nb // 2])
     # per stream: launches back to back -> the launch period of the step kernel on that stream, over all windows
     ev_ms = sum(evs[k][0].elapsed_time(evs[k][R]) for k in range(S)) / S / R
     tmax = torch.tensor([med_ms * 1e-3, wall_all], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -283,7 +294,7 @@ def main():
         value = agent_steps / wall
         b_alg = b_alg_per_agent_step(n_a, n_g_mean)
         f_alg = f_alg_per_agent_step(n_a, n_g_mean)
-        resets = sum(1 for t in range(W, W + R * K) if (t + 1) % EPISODE_LENGTH == 0)
+        resets = sum(1 for t in range(pre + W, pre + W + R * K) for k in range(S) if (t + 1 + phase[k]) % EPISODE_LENGTH == 0)
         kern_ms = ev_ms / K                                   # launch period of one stream
         per_launch = E / S * n_a                              # agent-steps of one launch (one shard)
         per_gpu = value / world                               # agent-steps/s of one GPU
@@ -308,9 +319,11 @@ def main():
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "timing": {"clock": "HIP events on the shard streams at the window boundaries; value = agent-steps of one "
-                                "window / median window duration, max over ranks",
-                       "windows": R, "steps_per_window": K, "window_ms_min_median_max": [win_ms[0], med_ms, win_ms[-1]],
+            "timing": {"clock": "HIP events on the shard streams at the window boundaries; windows shorter than an episode "
+                                "are averaged in blocks that span one; value = agent-steps of one window / median block, "
+                                "max over ranks",
+                       "windows": R, "steps_per_window": K, "windows_per_block": G,
+                       "window_ms_min_median_max": [win_ms[0], med_ms, win_ms[-1]],
                        "host_wall_ms_per_step_all_windows": wall_all / (R * K) * 1e3,
                        "untimed_settle_steps": max(SETTLE_STEPS, W)},
             "config": {"workload": f"{E} parallel assembly envs x {n_a} agents per GPU, random U(-1,1) actions "

@@ -390,16 +390,15 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
             // The cell block's rows go out as buffer stores: resource = the observation block of the wave's first
             // environment onwards, vector offset = the lane's column (plus its environment's distance from the first),
-            // scalar offset = the row, so a row store needs no vector address arithmetic; non-temporal when the launch's
-            // observations are too large to stay in the last-level cache anyway (P.obs_nt).
+            // scalar offset = the row, so a row store needs no vector address arithmetic; non-temporal, as the rows of a
+            // large swarm are written once and read by a later kernel.  (A run-time choice between the two store
+            // policies here, per store or per copy of the whole loop, doubled the step time of a 1024-agent swarm.)
             const int e_first = __builtin_amdgcn_readfirstlane(e);
             const __amdgpu_buffer_rsrc_t obs_rs =
                 __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e_first * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
             const int olb = ((e - e_first) * P.obs_dim * n_a + i) * 4;
-            const bool obs_nt = P.obs_nt != 0;
             auto ostore = [&](int r, float v) {
-                if (obs_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, r * n_a * 4, 2);
-                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, r * n_a * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, r * n_a * 4, 2);
             };
             auto slot = [&](int k, int cell) {
                 float gx = 0.f, gy = 0.f;

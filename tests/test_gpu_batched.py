@@ -177,6 +177,28 @@ def test_kernel_schedules_agree_bit_for_bit(torch_cuda, monkeypatch):
         assert torch.allclose(st, ref_stats, rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("n_a,E", [(30, 301), (256, 3)])
+def test_store_policies_agree_bit_for_bit(torch_cuda, monkeypatch, n_a, E):
+    """Observation rows stored non-temporal (schedule + 64) or the ordinary way (+ 128): identical outputs, in the
+    multi-wave kernel and in the large-swarm kernel."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    outs = []
+    for bits in (64, 128):
+        _schedule(monkeypatch, 4 + bits)
+        env = BatchedAssemblyEnv(E, n_a, seed=5)
+        env.reset()
+        rec = []
+        for t in range(6):
+            obs, rew, _, _, prior = env.step(env.random_actions())
+            rec.append([x.clone() for x in (obs, rew, prior, env.p, env.dp, env.neighbor_index, env.in_flags, env.nearest_cell)])
+        outs.append((rec, env.stats.clone()))
+    for t in range(6):
+        for a, b in zip(outs[0][0][t], outs[1][0][t]):
+            assert torch.equal(a, b), f"step {t}"
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_converged_regime_teacher_forced(torch_cuda):
     """Agents packed inside the shape: sensed lists above 80, occupied cells, contacts,
     rewards — the regime random actions rarely reach."""
