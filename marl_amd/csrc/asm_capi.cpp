@@ -74,7 +74,8 @@ int fast_t_setting() { return schedule_setting() & 15; }
 // the last-level cache until the next kernel reads it, and stored the ordinary way it pushes the grids and the state
 // out (16384 environments of 30 agents per GPU: 165 against 139 us per step); a smaller batch is better left in the cache
 // for its reader (4096 environments: the policy kernel behind the step runs 3.5 % faster).  Bit 6 of the schedule
-// setting (+64) forces them on, bit 7 (+128) off.
+// setting (+64) forces them on, bit 7 (+128) off.  (The multi-wave kernel only; the large-swarm kernel always stores
+// its cell block non-temporal.)
 int obs_nt_for(const DevParams &P)
 {
     const int s = schedule_setting();
