@@ -144,14 +144,49 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     constexpr int xat = 0;
 #endif
     // ---- P0: grid and state into LDS (all global loads issued before the first LDS write) ----
+    // Every load of this phase that does not depend on another one is issued before anything waits: a load inside a
+    // branch ("environment e0 + 1 exists ? load : 0") gets its own wait inside that branch, and a chain of such waits was
+    // six round trips to memory long.  Hence indices clamped to the last environment instead of branches, the values
+    // discarded afterwards where the environment does not exist, and the widest loads (the grid rows) first.
     const int e0 = blockIdx.x * 2;
-    const int ng0 = e0 < P.E ? clamp_ng(ng_g[e0], P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng_g[e0 + 1], P.n_g_max) : 0;
+    const int e_last = P.E - 1, e0c = e0 < e_last ? e0 : e_last, e1c = e0 + 1 < e_last ? e0 + 1 : e_last, ec = es ? e1c : e0c;
+    [[maybe_unused]] float4 gv[4];
+    if constexpr (T == 4) {                                         // one coordinate row per wave: its loads go first
+        const float *src = grid_g + ((size_t)((sub >> 1) ? e1c : e0c) * 2 + (sub & 1)) * NGP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = (q * 64 + l) * 4;
+            gv[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+            if (q * 256 < NGP && c < NGP) gv[q] = *reinterpret_cast<const float4 *>(src + c);
+        }
+    }
+    // Everything the dynamics phase reads from memory is requested here too: the state and the actions (first wave) and
+    // the prior's neighbour list, in-shape flag and nearest cell of the previous observation (second wave).
+    float act_x = 0.f, act_y = 0.f;
+    int nb_pre[6] = {-1, -1, -1, -1, -1, -1}, inf_pre = 0, near_pre = 0;
+    const bool prior_on = !P.observe_only && P.prior && prior_g;
+    float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;              // unused lanes: far from every agent AND from the padding cells (+1e30)
+    if (sub == 0 && active) {
+        const size_t o = (size_t)e * 2 * n_a;
+        sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
+        if (!P.observe_only) { act_x = act_g[o + i]; act_y = act_g[o + n_a + i]; }
+    }
+    if (sub == SUB_PRIOR && active && prior_on) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+        inf_pre = inflag_g[(size_t)e * n_a + i]; near_pre = nearest_g[(size_t)e * n_a + i];   // (unused by a step that recomputes the target)
+    }
+    const int ng0r = ng_g[e0c], ng1r = ng_g[e1c];
+    [[maybe_unused]] int sid0r = 0, sid1r = 0;
+    if constexpr (LAT) { sid0r = lat.shape_id[e0c]; sid1r = lat.shape_id[e1c]; }
+    const double l_cell_r = lcell_g[ec];
+    const int ng0 = e0 < P.E ? clamp_ng(ng0r, P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng1r, P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
 #ifdef ASM_DIAG
     asm volatile("" :: "s"(ng0));
     const unsigned long long dg_a = __builtin_readcyclecounter();   // the first loaded value (n_g) is there
 #endif
-    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    const double l_cell = env_ok ? l_cell_r : 1.0;
     // lattice path: the two environments' shape tables (row windows + boundary list, 1664 bytes each) go into the unused
     // part of the grid area, between the x rows and the y rows
     static_assert(!LAT || T == 4, "the lattice path is scheduled for four waves");
@@ -166,8 +201,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // runs under the dynamics instead of delaying the first barrier.
     [[maybe_unused]] int sid0 = 0, sid1 = 0;
     if constexpr (LAT) {
-        sid0 = e0 < P.E ? lat.shape_id[e0] : 0; sid1 = e0 + 1 < P.E ? lat.shape_id[e0 + 1] : 0;
-        if (env_ok) { xf_c = lat.xform[(size_t)e * 4]; xf_s = lat.xform[(size_t)e * 4 + 1]; xf_ox = lat.xform[(size_t)e * 4 + 2]; xf_oy = lat.xform[(size_t)e * 4 + 3]; }
+        sid0 = e0 < P.E ? sid0r : 0; sid1 = e0 + 1 < P.E ? sid1r : 0;
+        xf_c = lat.xform[(size_t)ec * 4]; xf_s = lat.xform[(size_t)ec * 4 + 1]; xf_ox = lat.xform[(size_t)ec * 4 + 2]; xf_oy = lat.xform[(size_t)ec * 4 + 3];
     }
     auto lat_loads = [&]() {
 #ifdef ASM_DIAG
@@ -177,7 +212,8 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
 #endif
         sid0 = sid0 < 0 ? 0 : (sid0 >= lat.n_shapes ? lat.n_shapes - 1 : sid0);
         sid1 = sid1 < 0 ? 0 : (sid1 >= lat.n_shapes ? lat.n_shapes - 1 : sid1);
-        lat_nb0 = e0 < P.E ? lat.shapes[sid0].n_boundary : 0; lat_nb1 = e0 + 1 < P.E ? lat.shapes[sid1].n_boundary : 0;
+        const int nb0r = lat.shapes[sid0].n_boundary, nb1r = lat.shapes[sid1].n_boundary;      // (sid clamped above: always a valid shape)
+        lat_nb0 = e0 < P.E ? nb0r : 0; lat_nb1 = e0 + 1 < P.E ? nb1r : 0;
         const asm_lattice_shape *sh = lat.shapes + (es ? sid1 : sid0);
         lat_cols = sh->cols; lat_rows = sh->rows; lat_x0 = sh->x0; lat_y0 = sh->y0; lat_invl = 1.0 / sh->l_cell;
         if (tid < 2 * LAT_TAB_VEC) {
@@ -185,23 +221,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             lat_tv = reinterpret_cast<const uint4 *>(lat.shapes + (h ? sid1 : sid0))[tid - h * LAT_TAB_VEC];
         }
     };
-    // Everything the dynamics phase reads from memory is requested here, with the first round trip: the actions (first
-    // wave) and the prior's neighbour list, in-shape flag and nearest cell of the previous observation (second wave).
-    float act_x = 0.f, act_y = 0.f;
-    int nb_pre[6] = {-1, -1, -1, -1, -1, -1}, inf_pre = 0, near_pre = 0;
-    const bool prior_on = !P.observe_only && P.prior && prior_g;
     {
-        float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;          // unused lanes: far from every agent AND from the padding cells (+1e30)
-        if (sub == 0 && active) {
-            const size_t o = (size_t)e * 2 * n_a;
-            sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
-            if (!P.observe_only) { act_x = act_g[o + i]; act_y = act_g[o + n_a + i]; }
-        }
-        if (sub == SUB_PRIOR && active && prior_on) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
-            if (!P.recompute) { inf_pre = inflag_g[(size_t)e * n_a + i]; near_pre = nearest_g[(size_t)e * n_a + i]; }
-        }
         // The four coordinate rows (2 environments x {x, y}) are dealt out to the waves, so the row and its n_g are
         // wave-uniform and a lane's float4 index is just l, l + 64, ...; cells beyond n_g become far-away padding.
         for (int row = sub; row < 4; row += T) {
@@ -209,13 +229,17 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const bool row_ok = e0 + h < P.E;
             const float *src = grid_g + ((size_t)(e0 + h) * 2 + (row & 1)) * NGP;
             float *dst = L.g + (size_t)(row & 1) * ASM_GY_OFF + (size_t)h * NGP;
-            for (int base = 0; base < NGP; base += 64 * 4 * 4) {
+            for (int base = 0; base < NGP; base += 64 * 4 * 4) {        // (one trip: a row has at most 1024 cells)
                 float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = base + (q * 64 + l) * 4;
-                    v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
-                    if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
+                    if constexpr (T == 4) {
+                        v[q] = row_ok ? gv[q] : make_float4(1e30f, 1e30f, 1e30f, 1e30f);     // requested at the top
+                    } else {
+                        v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
+                        if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
+                    }
                 }
                 if constexpr (LAT) if (base == 0) lat_loads();      // T = 4: every wave passes here exactly once
 #ifdef ASM_DIAG
