@@ -176,10 +176,12 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
         inf_pre = inflag_g[(size_t)e * n_a + i]; near_pre = nearest_g[(size_t)e * n_a + i];   // (unused by a step that recomputes the target)
     }
+    const double l_cell_r = lcell_g[ec];
+    [[maybe_unused]] double xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
+    if constexpr (LAT) { xf_c = lat.xform[(size_t)ec * 4]; xf_s = lat.xform[(size_t)ec * 4 + 1]; xf_ox = lat.xform[(size_t)ec * 4 + 2]; xf_oy = lat.xform[(size_t)ec * 4 + 3]; }
     const int ng0r = ng_g[e0c], ng1r = ng_g[e1c];
     [[maybe_unused]] int sid0r = 0, sid1r = 0;
     if constexpr (LAT) { sid0r = lat.shape_id[e0c]; sid1r = lat.shape_id[e1c]; }
-    const double l_cell_r = lcell_g[ec];
     const int ng0 = e0 < P.E ? clamp_ng(ng0r, P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng1r, P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
 #ifdef ASM_DIAG
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     constexpr int LAT_TAB_BYTES = 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS + 2 * ASM_LAT_NB, LAT_TAB_VEC = LAT_TAB_BYTES / 16;
     unsigned char *lat_tabs = reinterpret_cast<unsigned char *>(L.g + 2 * NGP + 64);
     [[maybe_unused]] int lat_cols = 0, lat_rows = 0, lat_nb0 = 0, lat_nb1 = 0;
-    [[maybe_unused]] double lat_x0 = 0, lat_y0 = 0, lat_invl = 1, xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
+    [[maybe_unused]] double lat_x0 = 0, lat_y0 = 0, lat_invl = 1;
     [[maybe_unused]] uint4 lat_tv = make_uint4(0, 0, 0, 0);
     // The shape ids first: everything else of the lattice hangs on them.  The dependent loads are issued after the grid
     // loads below and their data is not needed before P3 (the tables reach LDS after the first barrier, the compacted
@@ -202,7 +204,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     [[maybe_unused]] int sid0 = 0, sid1 = 0;
     if constexpr (LAT) {
         sid0 = e0 < P.E ? sid0r : 0; sid1 = e0 + 1 < P.E ? sid1r : 0;
-        xf_c = lat.xform[(size_t)ec * 4]; xf_s = lat.xform[(size_t)ec * 4 + 1]; xf_ox = lat.xform[(size_t)ec * 4 + 2]; xf_oy = lat.xform[(size_t)ec * 4 + 3];
     }
     auto lat_loads = [&]() {
 #ifdef ASM_DIAG
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 for (int q = 0; q < 4; ++q) {
                     const int c = base + (q * 64 + l) * 4;
                     if constexpr (T == 4) {
-                        v[q] = row_ok ? gv[q] : make_float4(1e30f, 1e30f, 1e30f, 1e30f);     // requested at the top
+                        v[q] = gv[q];                               // requested at the top (a missing environment has n_g = 0: all padding)
                     } else {
                         v[q] = make_float4(1e30f, 1e30f, 1e30f, 1e30f);
                         if (base + q * 256 < NGP && c < NGP && row_ok) v[q] = *reinterpret_cast<const float4 *>(src + c);
@@ -376,7 +377,11 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         int nb[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) nb[q] = nb_pre[q];
-        bool inf = inf_pre != 0; int near = near_pre;
+        // (the flag is handed over through an empty asm statement: otherwise its comparison is computed where the flag was
+        // requested, in the load phase, and every load issued before it is waited for there)
+        int inf_o = inf_pre, near = near_pre;
+        asm volatile("" : "+v"(inf_o), "+v"(near));
+        bool inf = inf_o != 0;
         if (P.recompute) {
             double smin; cell_pass<float, false>(P, true, px, py, gxe, gye, l, nullptr, nullptr, nullptr, smin, near);
             inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
