@@ -548,21 +548,23 @@ template <typename S>
 __device__ __forceinline__ void load_env(const DevParams &P, const EnvLds<S> &L, bool env_ok, bool active, int e,
                                          int i, int n_g, const S *p_g, const S *dp_g, const S *grid_g)
 {
-    for (int c = i; c < P.NGP; c += P.SL) {
-        S x = (S)1e30, y = (S)1e30;
-        if (env_ok && c < n_g) {
-            x = grid_g[(size_t)e * 2 * P.n_g_max + c];
-            y = grid_g[(size_t)e * 2 * P.n_g_max + P.n_g_max + c];
-        }
-        L.gx[c] = x; L.gy[c] = y;
-    }
-    if (active) {
+    // The loads do not depend on n_g (cells are read up to the row's capacity and padded by a select afterwards) nor on
+    // one another, and the state is requested first: a load inside "c < n_g ?" waits for n_g before it is even issued,
+    // and a load inside any branch is waited for inside that branch.
+    S sx = (S)1e30, sy = (S)1e30, su = (S)0, sv = (S)0;                     // unused slots: far away, so the chunked
+    if (active) {                                                            // pair screens never select them
         const size_t b = (size_t)e * 2 * P.n_a;
-        L.px[i] = p_g[b + i]; L.py[i] = p_g[b + P.n_a + i];
-        L.vx[i] = dp_g[b + i]; L.vy[i] = dp_g[b + P.n_a + i];
-    } else {                                                                 // unused slots: far away, so the chunked
-        L.px[i] = (S)1e30; L.py[i] = (S)1e30; L.vx[i] = (S)0; L.vy[i] = (S)0;   // pair screens never select them
+        sx = p_g[b + i]; sy = p_g[b + P.n_a + i]; su = dp_g[b + i]; sv = dp_g[b + P.n_a + i];
     }
+    const int e_c = e < P.E ? e : P.E - 1;
+    const S *gx_g = grid_g + (size_t)e_c * 2 * P.n_g_max, *gy_g = gx_g + P.n_g_max;
+    for (int c = i; c < P.NGP; c += P.SL) {
+        const int cc = c < P.n_g_max ? c : P.n_g_max - 1;
+        const S xr = gx_g[cc], yr = gy_g[cc];
+        const bool in = env_ok && c < n_g;
+        L.gx[c] = in ? xr : (S)1e30; L.gy[c] = in ? yr : (S)1e30;
+    }
+    L.px[i] = sx; L.py[i] = sy; L.vx[i] = su; L.vy[i] = sv;
 }
 
 // ---------------------------------------------------------------------------------
@@ -599,8 +601,13 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
 #ifdef ASM_EXITS
     const int xat = g_exit_at;
 #endif
-    const int n_g = env_ok ? clamp_ng(ng_g[e], P.n_g_max) : 0;
-    const double l_cell = env_ok ? lcell_g[e] : 1.0;
+    const int e_c = e < P.E ? e : P.E - 1;                          // loads with a clamped index instead of loads inside branches
+    const int ng_r = ng_g[e_c];
+    const double l_cell_r = lcell_g[e_c];
+    [[maybe_unused]] int sid_r = 0;
+    if constexpr (sizeof(S) == 4) { if (P.lat == 2) sid_r = lat.shape_id[e_c]; }
+    const int n_g = env_ok ? clamp_ng(ng_r, P.n_g_max) : 0;
+    const double l_cell = env_ok ? l_cell_r : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
     if (i == 0) *L.cnt = 0;
     // lattice path (large swarms, one environment per workgroup): the shape's tables into LDS now, the compacted
@@ -610,15 +617,14 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     [[maybe_unused]] int lat_sid = 0;
     if constexpr (sizeof(S) == 4) {
         if (P.lat == 2) {
-            lat_sid = env_ok ? lat.shape_id[e] : 0;
+            lat_sid = env_ok ? sid_r : 0;
             lat_sid = lat_sid < 0 ? 0 : (lat_sid >= lat.n_shapes ? lat.n_shapes - 1 : lat_sid);
             const asm_lattice_shape *sh = lat.shapes + lat_sid;
             for (int k = i; k < ASM_LAT_TAB_BYTES / 16; k += P.SL) reinterpret_cast<uint4 *>(L.lat)[k] = reinterpret_cast<const uint4 *>(sh)[k];
             LV.tab = L.lat; LV.cbx = reinterpret_cast<const float *>(L.lat + ASM_LAT_TAB_BYTES); LV.cby = LV.cbx + ASM_LAT_NB;
             LV.cols = sh->cols; LV.rows = sh->rows; LV.nb = env_ok ? sh->n_boundary : 0;
             LV.x0 = sh->x0; LV.y0 = sh->y0; LV.invl = 1.0 / sh->l_cell;
-            LV.c = 1; LV.s = 0; LV.ox = 0; LV.oy = 0;
-            if (env_ok) { LV.c = lat.xform[(size_t)e * 4]; LV.s = lat.xform[(size_t)e * 4 + 1]; LV.ox = lat.xform[(size_t)e * 4 + 2]; LV.oy = lat.xform[(size_t)e * 4 + 3]; }
+            LV.c = lat.xform[(size_t)e_c * 4]; LV.s = lat.xform[(size_t)e_c * 4 + 1]; LV.ox = lat.xform[(size_t)e_c * 4 + 2]; LV.oy = lat.xform[(size_t)e_c * 4 + 3];
         }
     }
     __syncthreads();
