@@ -653,6 +653,13 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     double npx = 0, npy = 0, nvx = 0, nvy = 0;
     int contacts = 0;
     if (active) {
+        // requested now, used behind the contact search: the actions and the prior's inputs (previous neighbour list,
+        // in-shape flag, nearest cell)
+        const float act_xr = act_g[(size_t)e * 2 * n_a + i], act_yr = act_g[(size_t)e * 2 * n_a + n_a + i];
+        int nb_r[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) nb_r[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+        const int inf_r = inflag_g[(size_t)e * n_a + i], near_r = nearest_g[(size_t)e * n_a + i];
         const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
         // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
         double fx = 0.0, fy = 0.0;
@@ -750,14 +757,16 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
         if (P.prior && prior_g) {
             int nb[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) nb[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
+            for (int q = 0; q < 6; ++q) nb[q] = nb_r[q];
             double tx, ty;
-            bool inf; int near;
+            // (handed over through an empty asm statement, so that the flag's comparison is not computed where the flag
+            // was requested, which would wait for it there)
+            int inf_o = inf_r, near = near_r;
+            asm volatile("" : "+v"(inf_o), "+v"(near));
+            bool inf = inf_o != 0;
             if (P.recompute) {
                 double smin; cell_pass<S, false>(P, true, px, py, L.gx, L.gy, i, nullptr, nullptr, nullptr, smin, near);
                 inf = sqrt(smin) < sqrt(2.0) * l_cell / 2;
-            } else {
-                inf = inflag_g[(size_t)e * n_a + i] != 0; near = nearest_g[(size_t)e * n_a + i];
             }
             if (inf) { tx = px; ty = py; } else { tx = (double)L.gx[near]; ty = (double)L.gy[near]; }  // CPP:896-901
             double f0, f1;
@@ -766,8 +775,8 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
         }
         // ---- integration: ENV:626-647 ----
         const float sens = (float)P.sens;
-        double ux = (double)(sens * act_g[(size_t)e * 2 * n_a + i]);             // ENV:627,633 (1 * float32)
-        double uy = (double)(sens * act_g[(size_t)e * 2 * n_a + n_a + i]);
+        double ux = (double)(sens * act_xr);                                     // ENV:627,633 (1 * float32)
+        double uy = (double)(sens * act_yr);
         double Fx = ux + fx, Fy = uy + fy;
         if (!P.periodic) { Fx = Fx + wfx + dfx; Fy = Fy + wfy + dfy; }           // ENV:633
         nvx = vx + (Fx / P.mass) * P.dt; nvy = vy + (Fy / P.mass) * P.dt;        // ENV:638-641
