@@ -49,22 +49,61 @@ def f_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
     return 15.0 * n_g_mean + 20.0 * (n_a - 1) + 2400.0
 
 
-PMC_FILES = ("r02_pmc.json", "r02_c4_pmc.json", "r01_pmc.json")
+def _profile_for(suffix: str, E: int, n_a: int, S: int):
+    """The newest committed profile summary profiles/rNN_*<suffix> taken on this workload, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_*" + suffix)), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            w = t["workload"]
+            if (w["envs_per_gpu"], w["agents"]) == (E, n_a) and w.get("streams", S) in (S, 1):
+                t["source"] = "profiles/" + os.path.basename(path)
+                return t
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
+    return None
 
 
 def measured_traffic(E: int, n_a: int, S: int):
-    """HBM bytes per step-kernel launch and VALU busy from the committed rocprofv3 PMC passes (profiles/*_pmc.json),
-    if one was taken on this workload; None otherwise (counters cannot be read from inside this process)."""
-    for name in PMC_FILES:
-        try:
-            with open(os.path.join(REPO, "profiles", name)) as f:
-                t = json.load(f)
-            if t["workload"] == {"envs_per_gpu": E, "agents": n_a, "streams": S}:
-                t["source"] = "profiles/" + name
-                return t
-        except (OSError, ValueError, KeyError):
-            pass
-    return None
+    """HBM bytes per step-kernel launch and the issue counters from the committed rocprofv3 PMC passes
+    (profiles/rNN_*pmc.json, written by tools/pmc_summary.py), if one was taken on this workload; None otherwise
+    (counters cannot be read from inside this process)."""
+    return _profile_for("pmc.json", E, n_a, S)
+
+
+def profiled_kernel(E: int, n_a: int, S: int):
+    """Name and average duration of the step kernel from the committed rocprofv3 --kernel-trace --stats run of this
+    workload (profiles/rNN_*kernel_trace.json, written by tools/kernel_stats_summary.py), or None."""
+    return _profile_for("kernel_trace.json", E, n_a, S)
+
+
+def step_kernel_name(code: int, periodic: bool, idx: int, nt: bool) -> str:
+    """The kernel asm_batch_step_f32 launches, from asm_debug_step_schedule's code (include/marl_amd_env.h)."""
+    T = code & 15
+    if T:
+        b = lambda v: "true" if v else "false"
+        return f"asmenv::k_step_fast<{T}, {b(periodic)}, {idx}, {b(code & 16)}, {b(nt)}>"
+    name = "asmenv::k_step<float>"
+    extras = [x for x, on in (("lattice path", code & 32), ("cell lists", code & 64), ("three launches", code & 128)) if on]
+    return name + (f" ({', '.join(extras)})" if extras else "")
+
+
+def limiter_note(tr, valu_bound: bool) -> str:
+    """What the committed counters say limits the kernel (one launch alone on the chip)."""
+    if not tr:
+        return "no counter pass committed for this workload"
+    vb, wa = tr.get("valu_busy"), tr.get("sq_wait_any_frac_of_wave_cycles")
+    if vb is None:
+        return "counter summary without VALU busy"
+    head = f"vector issue {vb:.2f} busy" + (f", waves waiting {wa:.2f} of their cycles" if wa is not None else "")
+    if vb >= 0.6:
+        kind = "limited by vector-instruction issue"
+    elif wa is not None and wa >= 0.4:
+        kind = "limited by latency: dependent instruction chains and memory round trips of the waves, not issue or bandwidth"
+    else:
+        kind = "neither issue- nor bandwidth-limited: occupancy / launch ramp"
+    return f"{head}: {kind}; roofline by {'FLOPs: fp32 VALU' if valu_bound else 'bytes: HBM'}"
 
 
 def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 20.0):
@@ -73,8 +112,10 @@ def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 20.0):
     import numpy as np
     import oracle_lib as ol
     from marl_amd.shapes import load_shapes
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    threads = max(1, min(threads, os.cpu_count() or 1))
+    # every core this process may run on (its affinity mask), unless OMP_NUM_THREADS names the host's CPU share
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = max(1, min(omp, usable) if omp > 0 else usable)
     kind = "port"
     if os.path.isfile(ol.REF_SO):
         try:
@@ -104,6 +145,7 @@ def cpu_baseline(n_a: int, r_avoid: float, target_seconds: float = 20.0):
     dt = run(E, T)
     ol.bind(None)
     return {"value": E * T * n_a / dt, "unit": "agent-steps/s", "cores": threads, "kind": kind,
+            "cores_usable": usable, "cores_limit": "OMP_NUM_THREADS" if 0 < omp < usable else "affinity mask",
             "sample": f"{E} envs x {n_a} agents x {T} steps, {dt:.1f} s wall on {threads} threads "
                       f"({'compiled reference AssemblyEnv.cpp' if kind == 'reference' else 'C port of the reference'} "
                       f"driven by the C step loop of oracle/asm_oracle.c)"}
@@ -302,6 +344,10 @@ def main():
         # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B).  30 agents: 10.4 FLOP/B -> HBM; 1024 agents: 34.7 -> fp32 VALU.
         valu_bound = f_alg / b_alg > VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         tr = measured_traffic(E, n_a, S)
+        kt = profiled_kernel(E, n_a, S)
+        env0 = shards.envs[0]
+        kname = step_kernel_name(env0.step_schedule(), args.periodic, {None: 0, "sensed": 1, "both": 2}[args.keep_indices],
+                                 E // S * env0.obs_dim_agent * n_a * 4 > (64 << 20))
         if valu_bound:
             achieved, peak, unit = per_gpu * f_alg / 1e12, VALU_PEAK_TFLOPS, "TFLOP/s"
         else:
@@ -344,11 +390,16 @@ def main():
                          # rocprof's VALUBusy formula on the same PMC passes (counters serialise the launches, so
                          # this is one launch alone on the chip)
                          "valu_busy_one_launch": tr.get("valu_busy") if tr else None,
-                         "issue_bound_note": "the 30-agent step is limited by vector-instruction issue, not by bandwidth "
-                                             "(see valu_busy_one_launch); its roofline by bytes is HBM",
+                         "limiter": limiter_note(tr, valu_bound),
                          "launches_in_flight": S, "alg_bytes_per_launch": per_launch * b_alg,
                          "alg_flops_per_launch": per_launch * f_alg,
-                         "kernel": "k_step_fast / k_step (asm_batch_step_f32)",
+                         "kernel": kname + " (asm_batch_step_f32)",
+                         # rocprofv3 --kernel-trace --stats of this workload, committed under profiles/: the kernel's own
+                         # average duration; the gap is this run's launch period of a stream minus that duration
+                         "kernel_profiled": kt["kernel"] if kt else None,
+                         "kernel_avg_us_profiled": kt["avg_us"] if kt else None,
+                         "launch_gap_us": (kern_ms * 1e3 - kt["avg_us"]) if kt else None,
+                         "kernel_trace_source": kt["source"] if kt else None,
                          # HIP events on each shard's stream around all its timed launches, / launches: the launch period
                          # of a stream = kernel duration (rocprofv3 --kernel-trace: profiles/) + dispatch gap
                          "avg_launch_ms": kern_ms,

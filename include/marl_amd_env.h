@@ -16,8 +16,13 @@
  *      pointers to double / int32 / bool, outputs overwritten in place, `void`
  *      return.  Each call copies its inputs to the GPU, runs the double-precision
  *      instantiation of the HIP kernels for one environment and copies the outputs
- *      back.  There is no CPU fallback: without a usable HIP device the call
- *      prints the HIP error and aborts.
+ *      back.  There is no CPU fallback.  The reference's symbols cannot fail and
+ *      never end the host process (assembly.py:144-145 only prints on a bad
+ *      mode); a call that cannot run here (no usable HIP device, any HIP error, an
+ *      unsupported argument) fills its outputs with NaN / -1 / false, leaves the
+ *      message in asm_last_error() and its code in asm_compat_status(), prints the
+ *      message once per process and returns.  MARL_AMD_ABORT_ON_ERROR=1 in the
+ *      environment turns such a failure into abort().
  *
  *  (B) The batched interface: E independent environments per launch, DEVICE
  *      pointers, fp32 state, a HIP stream argument, `int` status return
@@ -74,14 +79,20 @@ void calculateActionPrior(double *p_input, double *dp_input, double *a_prior_inp
                           double *grid_center_input, int *neighbor_index_input, double d_sen,
                           double r_avoid, double l_cell, int topo_nei_max, int n_a, int n_g, int dim);
 
+/* Status of the calling thread's last call of one of the five symbols above: 0, or the error code whose text
+ * asm_last_error() holds.  No counterpart in the reference (its symbols cannot fail); for hosts that want to
+ * raise instead of reading NaN. */
+int asm_compat_status(void);
+
 /*
- * _get_observation for callers that cannot allocate device memory: code running under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, layouts and
+ * _get_observation for callers that cannot allocate device memory: tight serving loops that must stay off the
+ * allocator, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, layouts and
  * results as _get_observation above (bit for bit); returns 0, or an error code with the text in asm_last_error().
  * The device staging area is a fixed 4 MiB array inside the library (one copy per GPU, held until the process
  * ends) instead of a workspace that grows on demand; a call whose arrays need more (about n_a = 1024 with the
  * default list capacities) is rejected.  The call makes no hipMalloc / hipFree / stream creation; it runs on the
- * legacy default stream of the current device and returns when the outputs are in the caller's arrays.  Every call
+ * legacy default stream of the current device with blocking copies and returns when the outputs are in the caller's
+ * arrays (so it cannot be recorded into a HIP graph: a stream capture in progress rejects such copies).  Every call
  * on one GPU uses that GPU's array: calls on the same GPU must not overlap (calls through this entry point are
  * serialised by the library; other work that touches the array does not exist).
  */
@@ -322,7 +333,7 @@ int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *cou
  * accumulation): what MADDPG.step -> DDPGAgent.step -> MLPNetwork.forward compute one environment at a time
  * (maddpg.py:72-87, agents.py:69-96 without the exploration noise, networks.py:33-44: Linear - leaky_relu three times,
  * Linear - tanh).  obs: [E][obs_dim][n_a] as the step writes it; act: [E][act_dim][n_a] as the step reads it.  Weights:
- * one 16-byte fragment of 8 bf16 per lane, packed by the caller (marl_amd/policy_kernel.py::pack_policy):
+ * one 16-byte fragment of 8 bf16 per lane, packed by the caller (marl_amd/policy_kernel.py: FusedPolicyBF16.repack):
  *   w1 [K1][H/32][64][8] (k-step s, row tile m, lane l, element j), K1 = ceil(obs_dim / 16):
  *       W1[32 m + (l & 31)][16 s + 8 (l >> 5) + j]
  *   w2, w3 [H/16][H/32][64][8]: W[32 m + (l & 31)][32 (s >> 1) + 16 (s & 1) + 8 (j >> 2) + 4 (l >> 5) + (j & 3)]

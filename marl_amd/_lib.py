@@ -43,7 +43,7 @@ class AsmLattice(C.Structure):
 
 # Every symbol include/marl_amd_env.h declares.
 EXPORTS = ["_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "calculateActionPrior",
-           "asm_default_params", "asm_obs_dim", "asm_abi_version", "asm_last_error", "asm_device_count",
+           "asm_default_params", "asm_obs_dim", "asm_abi_version", "asm_last_error", "asm_compat_status", "asm_device_count",
            "asm_batch_observe_f32", "asm_batch_step_f32", "asm_batch_reset_f32",
            "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_batch_rule_actions_f32", "asm_replay_gather_f32", "asm_replay_draw_indices",
            "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err", "asm_get_observation_noalloc", "asm_lattice_build",
@@ -69,6 +69,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(SO_PATH, C.RTLD_GLOBAL)
     lib.asm_last_error.restype = C.c_char_p
     lib.asm_abi_version.restype = C.c_int
+    lib.asm_compat_status.restype = C.c_int
     lib.asm_device_count.restype = C.c_int
     lib.asm_obs_dim.restype = C.c_int
     lib.asm_obs_dim.argtypes = [C.POINTER(AsmParams)]
@@ -119,6 +120,11 @@ def load() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise RuntimeError(f"{what} failed ({rc}): {load().asm_last_error().decode()}")
+
+
+def check_compat(what: str) -> None:
+    """After one of the five reference-named void calls: raise if it failed (its outputs are then NaN / -1)."""
+    check(load().asm_compat_status(), what)
 
 
 def default_params(n_a: int, n_g_max: int, r_avoid: float, **over) -> AsmParams:

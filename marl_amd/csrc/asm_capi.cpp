@@ -286,13 +286,25 @@ std::mutex g_compat_mutex;
 unsigned char *g_ws = nullptr;
 size_t g_ws_bytes = 0;
 
-[[noreturn]] void die(const char *what, hipError_t e)
+// The five reference symbols return void and the reference never ends its host process (assembly.py:144-145 only
+// prints on a bad mode).  A failed call here -- no usable HIP device, an unsupported argument -- therefore fills the
+// outputs with NaN / -1 / false so that the failure cannot pass for a result, leaves the message in asm_last_error(),
+// prints it once per process and returns.  MARL_AMD_ABORT_ON_ERROR=1 turns such a failure into abort().  There is no
+// CPU fallback either way.
+#define HIP_TRY(call) do { hipError_t _e = (call); if (_e != hipSuccess) return hip_fail((int)_e, #call); } while (0)
+
+thread_local int g_compat_rc = 0;                            // status of this thread's last call of one of the five (asm_compat_status)
+void compat_failed(const char *fn)
 {
-    std::fprintf(stderr, "libAssemblyEnv (HIP): %s failed: %s. This library has no CPU fallback.\n", what,
-                 hipGetErrorString(e));
-    std::abort();
+    static const bool abort_on_error = [] { const char *v = std::getenv("MARL_AMD_ABORT_ON_ERROR"); return v && std::atoi(v) != 0; }();
+    static std::atomic<bool> printed{false};
+    if (abort_on_error || !printed.exchange(true))
+        std::fprintf(stderr, "libAssemblyEnv (HIP): %s failed: %s. This library has no CPU fallback; the outputs of a failed "
+                             "call are NaN / -1 (further failures are reported through asm_last_error() only).\n", fn, g_err);
+    if (abort_on_error) std::abort();
 }
-#define HIP_OR_DIE(call) do { hipError_t _e = (call); if (_e != hipSuccess) die(#call, _e); } while (0)
+template <typename T> void fill_n(T *dst, size_t n, T v) { if (dst) for (size_t k = 0; k < n; ++k) dst[k] = v; }
+size_t count_or_0(long long n) { return n > 0 ? (size_t)n : 0; }
 
 // One call = inputs gathered into a pinned host buffer, ONE host-to-device copy, the kernel, ONE device-to-host copy
 // of the outputs, one stream synchronisation: the device workspace and the pinned buffer share a layout
@@ -303,25 +315,32 @@ struct Arena {
 };
 unsigned char *g_host = nullptr;                             // pinned mirror of g_ws
 hipStream_t g_stream = nullptr;
-void ensure_ws(size_t bytes)
+int ensure_ws(size_t bytes)
 {
-    if (!g_stream) HIP_OR_DIE(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    if (bytes <= g_ws_bytes) return;
-    if (g_ws) { HIP_OR_DIE(hipFree(g_ws)); HIP_OR_DIE(hipHostFree(g_host)); }
+    if (!g_stream) HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (bytes <= g_ws_bytes) return 0;
+    if (g_ws) { hipError_t e1 = hipFree(g_ws), e2 = hipHostFree(g_host); g_ws = nullptr; g_host = nullptr; g_ws_bytes = 0;
+                if (e1 != hipSuccess) return hip_fail((int)e1, "hipFree"); if (e2 != hipSuccess) return hip_fail((int)e2, "hipHostFree"); }
     bytes = bytes * 2 + 4096;                                // head-room: the sizes of a run rarely change
-    HIP_OR_DIE(hipMalloc((void **)&g_ws, bytes));
-    HIP_OR_DIE(hipHostMalloc((void **)&g_host, bytes, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&g_ws, bytes));
+    if (hipError_t e = hipHostMalloc((void **)&g_host, bytes, hipHostMallocDefault); e != hipSuccess) {
+        (void)hipFree(g_ws); g_ws = nullptr; g_host = nullptr;
+        return hip_fail((int)e, "hipHostMalloc");
+    }
     g_ws_bytes = bytes;
+    return 0;
 }
 template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(g_ws + off); }
 template <typename T> void put(size_t off, const T *src, size_t n) { std::memcpy(g_host + off, src, n * sizeof(T)); }
 template <typename T> void get(T *dst, size_t off, size_t n) { std::memcpy(dst, g_host + off, n * sizeof(T)); }
-void upload(size_t end) { HIP_OR_DIE(hipMemcpyAsync(g_ws, g_host, end, hipMemcpyHostToDevice, g_stream)); }
-void download(size_t begin, size_t end)
+int upload(size_t end) { HIP_TRY(hipMemcpyAsync(g_ws, g_host, end, hipMemcpyHostToDevice, g_stream)); return 0; }
+int download(size_t begin, size_t end)
 {
-    HIP_OR_DIE(hipMemcpyAsync(g_host + begin, g_ws + begin, end - begin, hipMemcpyDeviceToHost, g_stream));
-    HIP_OR_DIE(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpyAsync(g_host + begin, g_ws + begin, end - begin, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return 0;
 }
+#define TRY(expr) do { if (int _rc = (expr)) return _rc; } while (0)
 
 void compat_params(asm_params *a, int n_a, int n_g, int topo, int n_obs, int n_occ, double d_sen, double r_avoid,
                    const double *bpos)
@@ -330,12 +349,6 @@ void compat_params(asm_params *a, int n_a, int n_g, int topo, int n_obs, int n_o
     a->topo_nei_max = topo; a->num_obs_grid_max = n_obs; a->num_occupied_grid_max = n_occ;
     a->d_sen = d_sen; a->r_avoid = r_avoid;
     if (bpos) { a->half_w = (bpos[2] - bpos[0]) / 2.0; a->half_h = (bpos[1] - bpos[3]) / 2.0; }   // CPP:75-76
-}
-
-[[noreturn]] void die_msg(const char *fn)
-{
-    std::fprintf(stderr, "libAssemblyEnv (HIP): %s: %s\n", fn, g_err);
-    std::abort();
 }
 
 }  // namespace
@@ -407,6 +420,7 @@ int asm_obs_dim(const asm_params *p)
 int asm_abi_version(void) { return ASM_ABI_VERSION; }
 void asm_set_step_schedule(int waves) { g_schedule_override.store(waves, std::memory_order_relaxed); }
 const char *asm_last_error(void) { return g_err; }
+int asm_compat_status(void) { return g_compat_rc; }
 
 int asm_device_count(void)
 {
@@ -628,34 +642,46 @@ void _get_observation(double *p_in, double *dp_in, double *heading_in, double *o
 {
     (void)Vel_max;                                           // unused by the reference too (CPP:36)
     std::lock_guard<std::mutex> lk(g_compat_mutex);
-    if (dim != 2) { fail(1, "dim = %d: only 2 is supported", dim); die_msg("_get_observation"); }
-    asm_params a; compat_params(&a, n_a, n_g, topo_nei_max, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
-    a.is_boundary = condition[0] ? 0 : 1; a.is_con_self_state = condition[2] ? 1 : 0;
-    DevParams P;
-    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("_get_observation");
-    P.cartesian = condition[1] ? 1 : 0;
-    P.obs_dim = obs_dim_agent;
-    const int min_rows = (P.con_self ? 4 : 0) + 24 + (P.cartesian ? 4 + 2 * P.n_obs : 6);
-    if (obs_dim_agent < min_rows) { fail(1, "obs_dim_agent = %d < %d", obs_dim_agent, min_rows); die_msg("_get_observation"); }
-    const size_t na = (size_t)n_a, ng = (size_t)n_g;
-    Arena A;
-    size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_h = A.take<double>(2 * na);
-    size_t o_g = A.take<double>(2 * ng), o_ng = A.take<int>(1), o_lc = A.take<double>(1);
-    size_t o_obs = A.take<double>((size_t)obs_dim_agent * na), o_nbr = A.take<int>(na * 6), o_in = A.take<int>(na);
-    size_t o_near = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_occ = A.take<int>(na * P.n_occ);
-    ensure_ws(A.off);
-    put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_h, heading_in, 2 * na); put(o_g, grid_in, 2 * ng);
-    put(o_ng, &n_g, 1); put(o_lc, &l_cell, 1);
-    upload(o_obs);                                           // the inputs end where the outputs begin
-    HIP_OR_DIE(hipMemsetAsync(g_ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double), g_stream));   // CPP:49 zero-initialised
-    int rc = asmenv::launch_observe<double>(P, at<double>(o_p), at<double>(o_dp), at<double>(o_h), at<double>(o_g),
-                                            at<int>(o_ng), at<double>(o_lc), at<int>(o_nbr), at<int>(o_in),
-                                            at<int>(o_near), at<double>(o_obs), nullptr, at<int>(o_sen),
-                                            at<int>(o_occ), g_stream);
-    if (rc) die("_get_observation kernel launch", (hipError_t)rc);
-    download(o_obs, A.off);
-    get(obs_io, o_obs, (size_t)obs_dim_agent * na); get(nbr_io, o_nbr, na * 6); get(inflags_io, o_in, na);
-    get(sensed_io, o_sen, na * P.n_obs); get(occupied_io, o_occ, na * P.n_occ);
+    const int rc = [&]() -> int {
+        if (dim != 2) return fail(1, "dim = %d: only 2 is supported", dim);
+        if (n_g < 1) return fail(1, "n_g = %d", n_g);
+        asm_params a; compat_params(&a, n_a, n_g, topo_nei_max, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
+        a.is_boundary = condition[0] ? 0 : 1; a.is_con_self_state = condition[2] ? 1 : 0;
+        DevParams P;
+        TRY(make_dev_params(&a, 1, sizeof(double), &P));
+        P.cartesian = condition[1] ? 1 : 0;
+        P.obs_dim = obs_dim_agent;
+        const int min_rows = (P.con_self ? 4 : 0) + 24 + (P.cartesian ? 4 + 2 * P.n_obs : 6);
+        if (obs_dim_agent < min_rows) return fail(1, "obs_dim_agent = %d < %d", obs_dim_agent, min_rows);
+        const size_t na = (size_t)n_a, ng = (size_t)n_g;
+        Arena A;
+        size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_h = A.take<double>(2 * na);
+        size_t o_g = A.take<double>(2 * ng), o_ng = A.take<int>(1), o_lc = A.take<double>(1);
+        size_t o_obs = A.take<double>((size_t)obs_dim_agent * na), o_nbr = A.take<int>(na * 6), o_in = A.take<int>(na);
+        size_t o_near = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_occ = A.take<int>(na * P.n_occ);
+        TRY(ensure_ws(A.off));
+        put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_h, heading_in, 2 * na); put(o_g, grid_in, 2 * ng);
+        put(o_ng, &n_g, 1); put(o_lc, &l_cell, 1);
+        TRY(upload(o_obs));                                  // the inputs end where the outputs begin
+        HIP_TRY(hipMemsetAsync(g_ws + o_obs, 0, (size_t)obs_dim_agent * na * sizeof(double), g_stream));   // CPP:49 zero-initialised
+        if (int krc = asmenv::launch_observe<double>(P, at<double>(o_p), at<double>(o_dp), at<double>(o_h), at<double>(o_g),
+                                                     at<int>(o_ng), at<double>(o_lc), at<int>(o_nbr), at<int>(o_in),
+                                                     at<int>(o_near), at<double>(o_obs), nullptr, at<int>(o_sen),
+                                                     at<int>(o_occ), g_stream))
+            return hip_fail(krc, "_get_observation kernel launch");
+        TRY(download(o_obs, A.off));
+        get(obs_io, o_obs, (size_t)obs_dim_agent * na); get(nbr_io, o_nbr, na * 6); get(inflags_io, o_in, na);
+        get(sensed_io, o_sen, na * P.n_obs); get(occupied_io, o_occ, na * P.n_occ);
+        return 0;
+    }();
+    g_compat_rc = rc;
+    if (rc) {
+        const size_t na = count_or_0(n_a);
+        fill_n(obs_io, na * count_or_0(obs_dim_agent), std::nan(""));
+        fill_n(nbr_io, na * count_or_0(topo_nei_max), -1); fill_n(inflags_io, na, -1);
+        fill_n(sensed_io, na * count_or_0(num_obs_grid_max), -1); fill_n(occupied_io, na * count_or_0(num_occupied_grid_max), -1);
+        compat_failed("_get_observation");
+    }
 }
 
 void _get_reward(double *p_in, double *dp_in, double *heading_in, double *act_in, double *reward_io, double *bpos,
@@ -669,25 +695,31 @@ void _get_reward(double *p_in, double *dp_in, double *heading_in, double *act_in
     (void)dp_in; (void)heading_in; (void)act_in; (void)occupied_in; (void)l_cell; (void)is_collide_b2b;
     (void)is_collide_b2w; (void)coefficients; (void)dim;
     std::lock_guard<std::mutex> lk(g_compat_mutex);
-    asm_params a; compat_params(&a, n_a, n_g, 6, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
-    DevParams P;
-    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("_get_reward");
-    if (topo_nei_max < 1) { fail(1, "topo_nei_max = %d", topo_nei_max); die_msg("_get_reward"); }
-    P.topo = topo_nei_max;
-    const size_t na = (size_t)n_a, ng = (size_t)n_g;
-    Arena A;
-    size_t o_p = A.take<double>(2 * na), o_g = A.take<double>(2 * ng), o_nbr = A.take<int>(na * topo_nei_max);
-    size_t o_in = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_r = A.take<double>(na);
-    ensure_ws(A.off);
-    put(o_p, p_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
-    put(o_in, inflags_in, na); put(o_sen, sensed_in, na * P.n_obs);
-    upload(o_r);
-    int rc = asmenv::launch_reward_compat(P, at<double>(o_p), at<double>(o_g), n_g, at<int>(o_nbr), at<int>(o_in),
-                                          at<int>(o_sen), condition[0], condition[3], condition[4], at<double>(o_r),
-                                          g_stream);
-    if (rc) die("_get_reward kernel launch", (hipError_t)rc);
-    download(o_r, A.off);
-    get(reward_io, o_r, na);
+    const int rc = [&]() -> int {
+        if (n_g < 1) return fail(1, "n_g = %d", n_g);
+        if (topo_nei_max < 1) return fail(1, "topo_nei_max = %d", topo_nei_max);
+        asm_params a; compat_params(&a, n_a, n_g, 6, num_obs_grid_max, num_occupied_grid_max, d_sen, r_avoid, bpos);
+        DevParams P;
+        TRY(make_dev_params(&a, 1, sizeof(double), &P));
+        P.topo = topo_nei_max;
+        const size_t na = (size_t)n_a, ng = (size_t)n_g;
+        Arena A;
+        size_t o_p = A.take<double>(2 * na), o_g = A.take<double>(2 * ng), o_nbr = A.take<int>(na * topo_nei_max);
+        size_t o_in = A.take<int>(na), o_sen = A.take<int>(na * P.n_obs), o_r = A.take<double>(na);
+        TRY(ensure_ws(A.off));
+        put(o_p, p_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
+        put(o_in, inflags_in, na); put(o_sen, sensed_in, na * P.n_obs);
+        TRY(upload(o_r));
+        if (int krc = asmenv::launch_reward_compat(P, at<double>(o_p), at<double>(o_g), n_g, at<int>(o_nbr), at<int>(o_in),
+                                                   at<int>(o_sen), condition[0], condition[3], condition[4], at<double>(o_r),
+                                                   g_stream))
+            return hip_fail(krc, "_get_reward kernel launch");
+        TRY(download(o_r, A.off));
+        get(reward_io, o_r, na);
+        return 0;
+    }();
+    g_compat_rc = rc;
+    if (rc) { fill_n(reward_io, count_or_0(n_a), std::nan("")); compat_failed("_get_reward"); }
 }
 
 void _sf_b2b_all(double *p_in, double *sf_io, double *d_edge_in, bool *collide_in, double *bpos, double *d_center_in,
@@ -696,19 +728,24 @@ void _sf_b2b_all(double *p_in, double *sf_io, double *d_edge_in, bool *collide_i
     (void)dim;
     std::lock_guard<std::mutex> lk(g_compat_mutex);
     if (n_a < 1) return;
-    const size_t na = (size_t)n_a;
-    Arena A;
-    size_t o_p = A.take<double>(2 * na), o_de = A.take<double>(na * na), o_dc = A.take<double>(na * na);
-    size_t o_c = A.take<bool>(na * na), o_sf = A.take<double>(2 * na);
-    ensure_ws(A.off);
-    put(o_p, p_in, 2 * na); put(o_de, d_edge_in, na * na); put(o_dc, d_center_in, na * na); put(o_c, collide_in, na * na);
-    upload(o_sf);
-    const double hw = (bpos[2] - bpos[0]) / 2.0, hh = (bpos[1] - bpos[3]) / 2.0;                   // CPP:776-777
-    int rc = asmenv::launch_sf_b2b_compat(at<double>(o_p), at<double>(o_de), at<bool>(o_c), at<double>(o_dc), n_a,
-                                          k_ball, is_periodic, hw, hh, at<double>(o_sf), g_stream);
-    if (rc) die("_sf_b2b_all kernel launch", (hipError_t)rc);
-    download(o_sf, A.off);
-    get(sf_io, o_sf, 2 * na);
+    const int rc = [&]() -> int {
+        const size_t na = (size_t)n_a;
+        Arena A;
+        size_t o_p = A.take<double>(2 * na), o_de = A.take<double>(na * na), o_dc = A.take<double>(na * na);
+        size_t o_c = A.take<bool>(na * na), o_sf = A.take<double>(2 * na);
+        TRY(ensure_ws(A.off));
+        put(o_p, p_in, 2 * na); put(o_de, d_edge_in, na * na); put(o_dc, d_center_in, na * na); put(o_c, collide_in, na * na);
+        TRY(upload(o_sf));
+        const double hw = (bpos[2] - bpos[0]) / 2.0, hh = (bpos[1] - bpos[3]) / 2.0;               // CPP:776-777
+        if (int krc = asmenv::launch_sf_b2b_compat(at<double>(o_p), at<double>(o_de), at<bool>(o_c), at<double>(o_dc), n_a,
+                                                   k_ball, is_periodic, hw, hh, at<double>(o_sf), g_stream))
+            return hip_fail(krc, "_sf_b2b_all kernel launch");
+        TRY(download(o_sf, A.off));
+        get(sf_io, o_sf, 2 * na);
+        return 0;
+    }();
+    g_compat_rc = rc;
+    if (rc) { fill_n(sf_io, 2 * (size_t)n_a, std::nan("")); compat_failed("_sf_b2b_all"); }
 }
 
 void _get_dist_b2w(double *p_in, double *r_in, double *d_b2w_io, bool *coll_io, int dim, int n_a, double *bpos)
@@ -716,17 +753,22 @@ void _get_dist_b2w(double *p_in, double *r_in, double *d_b2w_io, bool *coll_io, 
     (void)dim;
     std::lock_guard<std::mutex> lk(g_compat_mutex);
     if (n_a < 1) return;
-    const size_t na = (size_t)n_a;
-    Arena A;
-    size_t o_p = A.take<double>(2 * na), o_r = A.take<double>(na), o_d = A.take<double>(4 * na), o_c = A.take<bool>(4 * na);
-    ensure_ws(A.off);
-    put(o_p, p_in, 2 * na); put(o_r, r_in, na);
-    upload(o_d);
-    int rc = asmenv::launch_dist_b2w_compat(at<double>(o_p), at<double>(o_r), n_a, bpos, at<double>(o_d), at<bool>(o_c),
-                                            g_stream);
-    if (rc) die("_get_dist_b2w kernel launch", (hipError_t)rc);
-    download(o_d, A.off);
-    get(d_b2w_io, o_d, 4 * na); get(coll_io, o_c, 4 * na);
+    const int rc = [&]() -> int {
+        const size_t na = (size_t)n_a;
+        Arena A;
+        size_t o_p = A.take<double>(2 * na), o_r = A.take<double>(na), o_d = A.take<double>(4 * na), o_c = A.take<bool>(4 * na);
+        TRY(ensure_ws(A.off));
+        put(o_p, p_in, 2 * na); put(o_r, r_in, na);
+        TRY(upload(o_d));
+        if (int krc = asmenv::launch_dist_b2w_compat(at<double>(o_p), at<double>(o_r), n_a, bpos, at<double>(o_d), at<bool>(o_c),
+                                                     g_stream))
+            return hip_fail(krc, "_get_dist_b2w kernel launch");
+        TRY(download(o_d, A.off));
+        get(d_b2w_io, o_d, 4 * na); get(coll_io, o_c, 4 * na);
+        return 0;
+    }();
+    g_compat_rc = rc;
+    if (rc) { fill_n(d_b2w_io, 4 * (size_t)n_a, std::nan("")); fill_n(coll_io, 4 * (size_t)n_a, false); compat_failed("_get_dist_b2w"); }
 }
 
 void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, double *grid_in, int *nbr_in, double d_sen,
@@ -734,27 +776,33 @@ void calculateActionPrior(double *p_in, double *dp_in, double *a_prior_io, doubl
 {
     (void)dim;
     std::lock_guard<std::mutex> lk(g_compat_mutex);
-    asm_params a; compat_params(&a, n_a, n_g, 6, 80, 200, d_sen, r_avoid, nullptr);
-    DevParams P;
-    if (make_dev_params(&a, 1, sizeof(double), &P)) die_msg("calculateActionPrior");
-    if (topo_nei_max < 1 || topo_nei_max > 6) { fail(1, "topo_nei_max = %d: supported 1..6", topo_nei_max); die_msg("calculateActionPrior"); }
-    P.topo = topo_nei_max;
-    const size_t na = (size_t)n_a, ng = (size_t)n_g;
-    Arena A;
-    size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_g = A.take<double>(2 * ng);
-    size_t o_nbr = A.take<int>(na * topo_nei_max), o_a = A.take<double>(2 * na);
-    ensure_ws(A.off);
-    put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
-    upload(o_a);
-    int rc = asmenv::launch_prior_compat(P, at<double>(o_p), at<double>(o_dp), at<double>(o_g), n_g, at<int>(o_nbr),
-                                         l_cell, at<double>(o_a), g_stream);
-    if (rc) die("calculateActionPrior kernel launch", (hipError_t)rc);
-    download(o_a, A.off);
-    get(a_prior_io, o_a, 2 * na);
+    const int rc = [&]() -> int {
+        if (n_g < 1) return fail(1, "n_g = %d", n_g);
+        if (topo_nei_max < 1 || topo_nei_max > 6) return fail(1, "topo_nei_max = %d: supported 1..6", topo_nei_max);
+        asm_params a; compat_params(&a, n_a, n_g, 6, 80, 200, d_sen, r_avoid, nullptr);
+        DevParams P;
+        TRY(make_dev_params(&a, 1, sizeof(double), &P));
+        P.topo = topo_nei_max;
+        const size_t na = (size_t)n_a, ng = (size_t)n_g;
+        Arena A;
+        size_t o_p = A.take<double>(2 * na), o_dp = A.take<double>(2 * na), o_g = A.take<double>(2 * ng);
+        size_t o_nbr = A.take<int>(na * topo_nei_max), o_a = A.take<double>(2 * na);
+        TRY(ensure_ws(A.off));
+        put(o_p, p_in, 2 * na); put(o_dp, dp_in, 2 * na); put(o_g, grid_in, 2 * ng); put(o_nbr, nbr_in, na * topo_nei_max);
+        TRY(upload(o_a));
+        if (int krc = asmenv::launch_prior_compat(P, at<double>(o_p), at<double>(o_dp), at<double>(o_g), n_g, at<int>(o_nbr),
+                                                  l_cell, at<double>(o_a), g_stream))
+            return hip_fail(krc, "calculateActionPrior kernel launch");
+        TRY(download(o_a, A.off));
+        get(a_prior_io, o_a, 2 * na);
+        return 0;
+    }();
+    g_compat_rc = rc;
+    if (rc) { fill_n(a_prior_io, 2 * count_or_0(n_a), std::nan("")); compat_failed("calculateActionPrior"); }
 }
 
 // ------------------------------------------------------------------------------
-// _get_observation for callers that cannot allocate (HIP graph capture around them, serving loops, harnesses that
+// _get_observation for callers that cannot allocate (serving loops that must not touch the allocator, harnesses that
 // forbid hipMalloc): the device staging area of the call is a file-scope device array instead of the growing
 // hipMalloc'ed workspace above, the copies go straight between the caller's arrays and that array, and the work
 // runs on the legacy default stream.  Nothing here allocates, frees or creates a stream.

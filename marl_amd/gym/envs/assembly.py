@@ -168,6 +168,7 @@ class AssemblySwarmEnv(Env):
             c.c_double(self.Vel_max), c.c_int(self.topo_nei_max), c.c_int(self.num_obs_grid_max),
             c.c_int(self.num_occupied_grid_max), c.c_int(self.n_a), c.c_int(self.n_g), c.c_int(self.obs_dim_agent),
             c.c_int(self.dim), _bool(cond))
+        _lib.check_compat("_get_observation")          # the C symbol is void and never ends the process; this class raises
         return self.obs
 
     def _get_reward(self, a):
@@ -185,6 +186,7 @@ class AssemblySwarmEnv(Env):
             c.c_int(self.topo_nei_max), c.c_int(self.num_obs_grid_max), c.c_int(self.num_occupied_grid_max),
             c.c_int(self.n_a), c.c_int(self.n_g), c.c_int(self.dim), _bool(cond),
             _bool(np.ascontiguousarray(self.is_collide_b2b)), _bool(self.is_collide_b2w), _dbl(coefficients))
+        _lib.check_compat("_get_reward")
         return reward_a
 
     def _get_dist_b2b(self):
@@ -204,6 +206,7 @@ class AssemblySwarmEnv(Env):
         """ENV:454-461 -> _get_dist_b2w."""
         self._lib._get_dist_b2w(_dbl(self.p), _dbl(self.size), _dbl(self.d_b2w), _bool(self.is_collide_b2w),
                                 ctypes.c_int(self.dim), ctypes.c_int(self.n_a), _dbl(self.boundary_pos))
+        _lib.check_compat("_get_dist_b2w")
 
     def _get_done(self):
         return np.zeros((1, self.n_a)).astype(bool)                   # ENV:475-477
@@ -222,6 +225,7 @@ class AssemblySwarmEnv(Env):
                                   _bool(np.ascontiguousarray(collide)), _dbl(self.boundary_pos),
                                   _dbl(np.ascontiguousarray(d_center)), ctypes.c_int(self.n_a), ctypes.c_int(self.dim),
                                   ctypes.c_double(self.k_ball), ctypes.c_bool(self.is_periodic))
+            _lib.check_compat("_sf_b2b_all")
             if self.is_boundary:
                 self._get_dist_b2w()
                 hit = self.is_collide_b2w * self.d_b2w                                   # ENV:512
@@ -249,6 +253,7 @@ class AssemblySwarmEnv(Env):
                     _dbl(self.p), _dbl(self.dp), _dbl(a_prior), _dbl(self.grid_center), _i32(self.neighbor_index),
                     ctypes.c_double(self.d_sen), ctypes.c_double(self.r_avoid), ctypes.c_double(self.l_cell),
                     ctypes.c_int(self.topo_nei_max), ctypes.c_int(self.n_a), ctypes.c_int(self.n_g), ctypes.c_int(self.dim))
+                _lib.check_compat("calculateActionPrior")
             if self.dynamics_mode == "Cartesian":
                 u = a
             else:

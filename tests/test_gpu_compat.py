@@ -107,3 +107,26 @@ def test_five_symbols_on_lattice_state(hip):
         dc, de, co = ol.get_dist_b2b(p)
         assert np.array_equal(hip.sf_b2b_all(p, de, co, BPOS, dc), orc.sf_b2b_all(p, de, co, BPOS, dc))
         assert np.array_equal(hip.prior(p, dp, grid, nbr, 0.4, 0.26, l_cell), orc.prior(p, dp, grid, nbr, 0.4, 0.26, l_cell))
+
+
+def test_unsupported_argument_does_not_end_the_process(hip):
+    """The reference's symbols return void and never end their host (assembly.py:144-145 only prints): a call this
+    library cannot run leaves NaN / -1 in the outputs, a message and a status, and the next call works."""
+    from marl_amd import _lib
+    lib = _lib.load()
+    z = np.load(ROLLOUTS[0])
+    p = np.ascontiguousarray(z["p"][0]); dp = np.ascontiguousarray(z["dp"][0]); grid = np.ascontiguousarray(z["grid"])
+    heading = np.zeros_like(p)
+    d_sen, r_avoid, l_cell = float(z["d_sen"]), float(z["r_avoid"]), float(z["l_cell"])
+    obs, nbr, inf, sen, occ = hip.get_observation(p, dp, heading, BPOS, grid, d_sen, r_avoid, l_cell, topo=5)
+    assert lib.asm_compat_status() != 0 and b"topo_nei_max" in lib.asm_last_error()
+    assert np.isnan(obs).all() and (nbr == -1).all() and (inf == -1).all() and (sen == -1).all() and (occ == -1).all()
+    with pytest.raises(RuntimeError, match="topo_nei_max"):
+        _lib.check_compat("_get_observation")
+    pr = hip.prior(p, dp, grid, np.full((p.shape[1], 7), -1, np.int32), d_sen, r_avoid, l_cell)
+    assert lib.asm_compat_status() != 0 and np.isnan(pr).all()
+    # and the library still works afterwards
+    got = hip.get_observation(p, dp, heading, BPOS, grid, d_sen, r_avoid, l_cell,
+                              cond=(not bool(z["is_boundary"]), True, bool(z["is_con_self_state"]), False))
+    assert lib.asm_compat_status() == 0
+    assert np.array_equal(got[0], z["obs"][0]) and np.array_equal(got[1], z["nbr"][0])

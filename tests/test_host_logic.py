@@ -36,6 +36,25 @@ def test_params_struct_matches_header_defaults():
     assert _lib.load().asm_obs_dim(ctypes.byref(p)) == 188
 
 
+def test_bad_argument_to_a_reference_symbol_returns_instead_of_aborting():
+    """No GPU needed: the argument check comes before any HIP call.  The outputs are marked, the status is set."""
+    import ctypes as C
+    from marl_amd import _lib
+    lib = _lib.load()
+    n_a, n_g = 4, 8
+    p = np.zeros((2, n_a)); obs = np.zeros((192, n_a)); grid = np.zeros((2, n_g)); bpos = np.array([-2.4, 2.4, 2.4, -2.4])
+    nbr = np.zeros((n_a, 5), np.int32); inf = np.zeros(n_a, np.int32); sen = np.zeros((n_a, 80), np.int32); occ = np.zeros((n_a, 200), np.int32)
+    cond = np.array([False, True, True, False])
+    D = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)); I = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    lib._get_observation(D(p), D(p), D(p), D(obs), D(bpos), D(grid), I(nbr), I(inf), I(sen), I(occ), C.c_double(0.4),
+                         C.c_double(0.26), C.c_double(0.06), C.c_double(0.8), C.c_int(5), C.c_int(80), C.c_int(200),
+                         C.c_int(n_a), C.c_int(n_g), C.c_int(192), C.c_int(2), cond.ctypes.data_as(C.POINTER(C.c_bool)))
+    assert lib.asm_compat_status() != 0 and b"topo_nei_max" in lib.asm_last_error()
+    assert np.isnan(obs).all() and (nbr == -1).all() and (sen == -1).all() and (occ == -1).all() and (inf == -1).all()
+    with pytest.raises(RuntimeError, match="topo_nei_max"):
+        _lib.check_compat("_get_observation")
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from marl_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

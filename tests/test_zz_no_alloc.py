@@ -75,3 +75,24 @@ def test_noalloc_rejects_oversized_request():
             C.c_double(0.4), C.c_double(0.05), C.c_double(0.06), C.c_double(0.8), C.c_int(6), C.c_int(n_obs), C.c_int(n_occ),
             C.c_int(n_a), C.c_int(n_g), C.c_int(obs_dim), C.c_int(2), ol.b8(cond))
     assert rc != 0 and b"fixed device array" in lib.asm_last_error()
+
+
+def test_noalloc_calls_leave_device_memory_as_it_is():
+    """The property the entry point exists for: after a warm-up call (the code object and the symbol look-up),
+    further calls -- larger ones included -- do not change the device's free memory."""
+    import torch
+    from marl_amd import _lib
+    lib = _lib.load()
+    new = NoAlloc(lib)
+    rng = np.random.default_rng(11)
+    p, dp, heading, grid, l_cell = _state(rng, 8, 0)
+    new.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell)          # warm-up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for n_a, shape in ((30, 2), (256, 6), (100, 4), (30, 1)):
+        p, dp, heading, grid, l_cell = _state(rng, n_a, shape)
+        new.get_observation(p, dp, heading, BPOS, grid, 0.4, 0.26, l_cell)
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        assert free == free0, (n_a, free0 - free)
+    assert new.status == [0] * 5
