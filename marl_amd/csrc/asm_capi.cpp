@@ -211,10 +211,13 @@ int derive_dev_params(const asm_params *prm, int E, size_t state_bytes, DevParam
         if (T == 1 || T == 2 || T == 4) {
             // state 256 floats; grid: x rows of both environments, y rows ASM_GY_OFF floats further on, 64 own-position entries; masks; occupancy;
             // partials; flags; reward partials; slot lists (+ one emission round of padding) aliased with the word keys
-            const size_t bytes = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 + 64 * (size_t)P.MW + 4 * (size_t)P.W) + 16 * 64 * (size_t)T +
-                                 4 * 128 + 4 * 3 * 64 * (size_t)T +
-                                 std::max({2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW,
-                                           (size_t)(4 * 4 * ASM_LAT_NB + 4 * 64 * (ASM_LAT_NB / 32))});   // lattice path: compact boundary coordinates + word keys
+            const size_t common = 4 * (256 + ASM_GY_OFF + 2 * (size_t)P.NGP + 64 + 64 * (size_t)P.MW + 4 * (size_t)P.W);
+            const size_t bytes = common + 16 * 64 * (size_t)T + 4 * 128 + 4 * 3 * 64 * (size_t)T +
+                                 std::max(2 * 64 * (size_t)P.capp + 32, 4 * 64 * (size_t)P.MW);
+            // lattice path (T = 4): no partial rows, four ballot words, the reward partials in the shape tables' area,
+            // the compact boundary coordinates aliased with the slot lists
+            P.fast_lds_bytes_lat = (unsigned)(common + 4 * 128 + 16 +
+                                              std::max(2 * 64 * (size_t)P.capp + 32, (size_t)(4 * 4 * ASM_LAT_NB)));
             if (bytes <= 160 * 1024) { P.fast_T = T; P.fast_lds_bytes = (unsigned)bytes; }
         }
     }

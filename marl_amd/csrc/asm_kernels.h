@@ -38,7 +38,7 @@ struct DevParams {
     unsigned lds_env_bytes, lds_block_bytes;
     int fast_T, capp;               // k_step_fast: waves per workgroup (0: not eligible), padded slot count
     int obs_nt;                     // observation rows stored non-temporal (set per launch from the size of the observation array)
-    unsigned fast_lds_bytes;
+    unsigned fast_lds_bytes, fast_lds_bytes_lat;     // dynamic LDS of k_step_fast: all-cells path, lattice path
     int lat, lat_KO;                // lattice path: 0 off, 1 k_step_fast, 2 k_step (large swarms); lattice rows |k| <= lat_KO can hold an occupied cell
     float lat_cb;                   // band coefficient: storage rounding of the cell coordinates (see kernels_lattice.h)
     int state_rows;                 // state arrays of SL entries kept in LDS: 4 (px, py, vx, vy), or 2 for a part workgroup (velocities stay in global memory)

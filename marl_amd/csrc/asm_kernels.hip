@@ -102,9 +102,10 @@ static int launch_step_fast_t(const DevParams &P, const LatArgs &lat, float *p, 
                               float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
 {
     // three instantiations: the index-list outputs are compiled in only where they are asked for
+    const unsigned lds = P.lat ? P.fast_lds_bytes_lat : P.fast_lds_bytes;
     auto go = [&](auto kernel) {
-        if (int rc = set_lds(kernel, P.fast_lds_bytes)) return rc;
-        hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), P.fast_lds_bytes, st, P, lat, p, dp, act, grid, n_g,
+        if (int rc = set_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), lds, st, P, lat, p, dp, act, grid, n_g,
                            l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);
         LAUNCH_CHECK();
         return 0;

@@ -34,13 +34,15 @@ struct FastLds {
                                    // its relative position comes out as +0 without a select
     unsigned *mask;                // [64][MW]     sensed-cell bit mask per agent
     unsigned *occ;                 // [2][2W]      per env: occupancy words, then coverage words
-    uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity)
-    unsigned *fin;                 // [2][64]      nearest cell | contacts << 16 | in_flag << 31; then the list lengths (sensed-index output)
-    float *rpart;                  // [T][3][64]   per-wave partial reward sums
+    uint4 *part;                   // [T][64]      per-wave partial (min key, runner-up key, word, ambiguity), then what the statistics need;
+                                   //              absent on the lattice path
+    unsigned *fin;                 // [2][64]      nearest cell | in_flag << 31; then the list lengths (sparse compaction, sensed-index output)
+    unsigned *anyf;                // [2][2]       lattice path: ballots of the second / third wave -- it may have set sensed bits of the agent
+    float *rpart;                  // [T][3][64]   per-wave partial reward sums (lattice path: in the area of the shape tables, dead by then)
     unsigned short *sel;           // [64][CAPP]   compacted (sub-sampled) sensed list
 };
 
-__device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T)
+__device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevParams &P, int T, bool lat)
 {
     FastLds L;
     float *f = reinterpret_cast<float *>(smem);
@@ -49,9 +51,15 @@ __device__ __forceinline__ FastLds carve_fast(unsigned char *smem, const DevPara
     L.mask = reinterpret_cast<unsigned *>(L.g + ASM_GY_OFF + 2 * P.NGP + 64);   // 64: the y halves of the lanes' own-position entries
     L.occ = L.mask + 64 * P.MW;
     L.part = reinterpret_cast<uint4 *>(L.occ + 4 * P.W);
-    L.fin = reinterpret_cast<unsigned *>(L.part + 64 * T);
-    L.rpart = reinterpret_cast<float *>(L.fin + 128);
-    L.sel = reinterpret_cast<unsigned short *>(L.rpart + 3 * 64 * T);
+    L.fin = reinterpret_cast<unsigned *>(L.part + (lat ? 0 : 64 * T));
+    L.anyf = L.fin + 128;
+    if (lat) {
+        L.rpart = L.g + 2 * P.NGP + 64;                             // 3 KB of the 3.25 KB the two shape tables occupy until the cell phase is over
+        L.sel = reinterpret_cast<unsigned short *>(L.anyf + 4);
+    } else {
+        L.rpart = reinterpret_cast<float *>(L.fin + 128);
+        L.sel = reinterpret_cast<unsigned short *>(L.rpart + 3 * 64 * T);
+    }
     return L;
 }
 
@@ -97,6 +105,9 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #ifndef ASM_FAST_MINW
 #define ASM_FAST_MINW 1
 #endif
+#ifndef ASM_FAST_MINW_LAT
+#define ASM_FAST_MINW_LAT 5  // waves per SIMD the default lattice kernel is compiled for (96 registers; its LDS lets five workgroups share a CU)
+#endif
 #ifndef ASM_SPARSE_MAX
 #define ASM_SPARSE_MAX 64    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent (64: always;
                              // measured as fast as the lane-by-lane loop even when every agent senses cells)
@@ -107,7 +118,7 @@ template <int T, bool PER, int IDX, bool LAT, bool NT = false>   // PER: periodi
                                       // NT: the observation rows are stored non-temporal (launches whose observations are
                                       // too large to stay in the last-level cache until a later kernel reads them: then
                                       // they should not push the grids and the state out of it either)
-__global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P, LatArgs lat, float *p_g, float *dp_g, const float *act_g,
+__global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_LAT : ASM_FAST_MINW) void k_step_fast(DevParams P, LatArgs lat, float *p_g, float *dp_g, const float *act_g,
                                                       const float *grid_g, const int *ng_g, const double *lcell_g,
                                                       int *nbr_g, int *inflag_g, int *nearest_g, float *obs_g,
                                                       float *rew_g, float *prior_g, int *sensed_g, int *occup_g,
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const int e = blockIdx.x * 2 + es;
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
-    const FastLds L = carve_fast(smem, P, T);
+    const FastLds L = carve_fast(smem, P, T, LAT);
     float *gxe = L.g + (size_t)es * NGP, *gye = gxe + ASM_GY_OFF;
     unsigned *occ_e = L.occ + es * 2 * W, *cov_e = occ_e + W;
     constexpr int SUB_PRIOR = T > 1 ? 1 : 0;
@@ -149,6 +160,14 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // six round trips to memory long.  Hence indices clamped to the last environment instead of branches, the values
     // discarded afterwards where the environment does not exist, and the widest loads (the grid rows) first.
     const int e0 = blockIdx.x * 2;
+    // Per-agent arrays are addressed as a workgroup-uniform base (the first environment of the pair, scalar registers) plus a
+    // small per-lane element offset: no 64-bit vector address arithmetic, and nothing 64 bits wide kept per lane for it.
+    const int la = es * n_a + i, la2 = es * 2 * n_a + i;            // lane's agent among the pair's agents; its slot in a [2][n_a] array pair
+    float *const p_w = p_g + (size_t)e0 * 2 * n_a, *const dp_w = dp_g + (size_t)e0 * 2 * n_a;
+    const float *const act_w = act_g ? act_g + (size_t)e0 * 2 * n_a : nullptr;
+    float *const prior_w = prior_g ? prior_g + (size_t)e0 * 2 * n_a : nullptr;
+    int *const nbr_w = nbr_g + (size_t)e0 * n_a * 6, *const inflag_w = inflag_g + (size_t)e0 * n_a, *const nearest_w = nearest_g + (size_t)e0 * n_a;
+    float *const rew_w = rew_g ? rew_g + (size_t)e0 * n_a : nullptr;
     const int e_last = P.E - 1, e0c = e0 < e_last ? e0 : e_last, e1c = e0 + 1 < e_last ? e0 + 1 : e_last, ec = es ? e1c : e0c;
     [[maybe_unused]] float4 gv[4];
     if constexpr (T == 4) {                                         // one coordinate row per wave: its loads go first
@@ -167,14 +186,13 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     const bool prior_on = !P.observe_only && P.prior && prior_g;
     float sa = -1e30f, sb = -1e30f, sc = 0.f, sd = 0.f;              // unused lanes: far from every agent AND from the padding cells (+1e30)
     if (sub == 0 && active) {
-        const size_t o = (size_t)e * 2 * n_a;
-        sa = p_g[o + i]; sb = p_g[o + n_a + i]; sc = dp_g[o + i]; sd = dp_g[o + n_a + i];
-        if (!P.observe_only) { act_x = act_g[o + i]; act_y = act_g[o + n_a + i]; }
+        sa = p_w[la2]; sb = p_w[la2 + n_a]; sc = dp_w[la2]; sd = dp_w[la2 + n_a];
+        if (!P.observe_only) { act_x = act_w[la2]; act_y = act_w[la2 + n_a]; }
     }
     if (sub == SUB_PRIOR && active && prior_on) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_g[((size_t)e * n_a + i) * 6 + q];
-        inf_pre = inflag_g[(size_t)e * n_a + i]; near_pre = nearest_g[(size_t)e * n_a + i];   // (unused by a step that recomputes the target)
+        for (int q = 0; q < 6; ++q) nb_pre[q] = nbr_w[la * 6 + q];
+        inf_pre = inflag_w[la]; near_pre = nearest_w[la];   // (unused by a step that recomputes the target)
     }
     const double l_cell_r = lcell_g[ec];
     [[maybe_unused]] double xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
@@ -282,7 +300,6 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     // lattice path: the boundary cells' coordinates, compacted (the candidates of the nearest-cell pass).  Waves 2 and 3
     // gather them, one environment each, between the two barriers of the dynamics phase (the first publishes the tables).
     [[maybe_unused]] float *lat_cbx = reinterpret_cast<float *>(L.sel), *lat_cby = lat_cbx + 2 * ASM_LAT_NB;   // [2][NB] each, aliasing the slot lists
-    [[maybe_unused]] unsigned *lat_wkey = reinterpret_cast<unsigned *>(lat_cby + 2 * ASM_LAT_NB);            // [64][NB / 32]
     auto lat_compact = [&]() {
         if constexpr (LAT) {
             if (sub >= 2) {
@@ -390,15 +407,14 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         double f0, f1;
         prior_policy<float>(P, px, py, vx, vy, tx, ty, nb, L.px + es * 32, L.py + es * 32, L.vx + es * 32,
                             L.vy + es * 32, f0, f1);
-        prior_g[(size_t)e * 2 * n_a + i] = (float)f0; prior_g[(size_t)e * 2 * n_a + n_a + i] = (float)f1;
+        prior_w[la2] = (float)f0; prior_w[la2 + n_a] = (float)f1;
     }
     STAMP(2);
     __syncthreads();                                                // all reads of the old state done
     lat_compact();
     if (sub == 0 && active) {
         L.px[l] = npx; L.py[l] = npy; L.vx[l] = nvx; L.vy[l] = nvy;
-        const size_t o = (size_t)e * 2 * n_a;
-        p_g[o + i] = npx; p_g[o + n_a + i] = npy; dp_g[o + i] = nvx; dp_g[o + n_a + i] = nvy;
+        p_w[la2] = npx; p_w[la2 + n_a] = npy; dp_w[la2] = nvx; dp_w[la2 + n_a] = nvy;
     }
     __syncthreads();
     } else if constexpr (LAT) {
@@ -422,10 +438,46 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     auto ostore = [&](int row, float v) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, NT ? 2 : 0);
     };
-    double s6[6]; int j6[6];
+    int j6[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
+    for (int q = 0; q < 6; ++q) j6[q] = -1;
     double nn_min = __builtin_inf();
+    [[maybe_unused]] double dmin_lat = 0.0;                         // lattice path: the nearest cell's distance (fourth wave)
+    // Formation statistics (TRAIN:132-135; WRAP:48-165) in three independent pieces, each added by the wave that holds its
+    // inputs (one adding lane per entry and launch either way):
+    //   nearest-neighbour uniformity + contact pairs + step count, mean distance to the target cell, coverage.
+    auto stats_neighbours = [&](double nn, int cn) {
+        if (active && nn == 0.0) {                                  // an agent at this very position: WRAP:93-94 drops exact zeros
+            nn = __builtin_inf();
+#pragma nounroll
+            for (int j = 0; j < n_a; ++j) {
+                const double ex = (double)L.px[es * 32 + j] - px, ey = (double)L.py[es * 32 + j] - py, su = ex * ex + ey * ey;
+                if (su != 0 && su < nn) nn = su;
+            }
+        }
+        const double m = active ? sqrt(nn) : 0.0;
+#pragma unroll
+        for (int mm = 16; mm >= 1; mm >>= 1) cn += __shfl_xor(cn, mm, 32);
+        const double ms = half_sum(m);
+        const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
+        const double mean = ms / n_a, dv = active ? m - mean : 0.0;
+        const double var = half_sum(dv * dv) / n_a;
+        if (i == 0 && env_ok) {
+            double *st = stats_g + (size_t)e0 * 8 + es * 8;
+            stat_add(&st[3], (var - lo) / (hi - lo));               // WRAP:98-99
+            stat_add(&st[4], (double)cn); stat_add(&st[6], 1.0);
+        }
+    };
+    auto stats_target = [&](double dm) {
+        const double ds = half_sum(active ? dm : 0.0);
+        if (i == 0 && env_ok) stat_add(stats_g + (size_t)e0 * 8 + es * 8 + 5, ds / n_a);
+    };
+    auto stats_coverage = [&]() {
+        int ci = i < W ? __popc(cov_e[i]) : 0;
+#pragma unroll
+        for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
+        if (i == 0 && env_ok) stat_add(stats_g + (size_t)e0 * 8 + es * 8 + 2, n_g > 0 ? (double)ci / n_g : 0.0);   // WRAP:70; an environment without cells covers nothing
+    };
     [[maybe_unused]] const float hw32 = (float)P.half_w, hh32 = (float)P.half_h;
     if (sub == 0 && active && xat != 13) {
         // k nearest neighbours inside d_sen (_get_focused, CPP:633-703): fp32 screen, exact on candidates
@@ -474,8 +526,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         if (__ballot(redo)) {                                       // rare
             if (redo) {
+                double s6[6];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) j6[q] = -1;
+                for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
                 cand = cand_all;
                 while (cand) {                                      // ascending j: ties keep the lower index
                     const int j = __ffs(cand) - 1; cand &= cand - 1;
@@ -514,17 +567,19 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 }
                 wx = L.vx[es * 32 + j] - vxf; wy = L.vy[es * 32 + j] - vyf;      // CPP:86
             }
-            nbr_g[((size_t)e * n_a + i) * 6 + q] = j;               // CPP:103-105
+            nbr_w[la * 6 + q] = j;                                  // CPP:103-105
             const int r = r0 + 4 * q;
             ostore(r, rx); ostore(r + 1, ry); ostore(r + 2, wx); ostore(r + 3, wy);
         }
     }
     STAMP(4);
     if constexpr (LAT) {
-        // Lattice path (kernels_lattice.h).  Wave 0 has the k-NN pass above; waves 1..3 share the 15 lattice rows the
-        // sensing disc can cross (5 each); wave 3 also evaluates the four lattice sites around the agent exactly; all
-        // four share the words of the compacted boundary list (nearest-cell screen).
-        unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, lat_any = 0;   // lat_any: this wave may have set sensed bits of the lane
+        // Lattice path (kernels_lattice.h).  Four jobs, one per wave, all done when the barrier below is reached:
+        // wave 0 the k-NN pass above; waves 1 and 2 the 15 lattice rows the sensing disc can cross (odd / even rows);
+        // wave 3 the nearest cell from start to finish -- the four lattice sites around the agent, the screen of the
+        // compacted boundary cells, the exact comparison of the candidates -- with the in-shape flag and the target
+        // block.  No wave waits for another one's partial result, and nothing runs on one wave alone behind the barrier.
+        unsigned lat_any = 0;                                       // this wave may have set sensed bits of the lane
         if (sub != 0) {
             LatLane A;
             {
@@ -542,64 +597,136 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
             }
             const unsigned char *tab = lat_tabs + es * LAT_TAB_BYTES;
-            unsigned *mrow = L.mask + (size_t)l * MW;
-            unsigned und = 0;                                       // bits 2t, 2t + 1: sensed / occupancy run of row t undecided
+            if (sub != 3) {
+                unsigned *mrow = L.mask + (size_t)l * MW;
+                unsigned und = 0;                                   // bits 2t, 2t + 1: sensed / occupancy run of row t undecided
+                const int kfirst = -7 + (sub - 1), nrows = sub == 1 ? 8 : 7;    // wave-uniform
 #pragma unroll 1
-            for (int t = 0; t < 5; ++t) {
-                const int k = -7 + (sub - 1) + 3 * t;               // wave-uniform
-                const unsigned r = lat_row(P, A, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e);
-                und |= (r & 3u) << (2 * t);
-                lat_any |= r;                                       // bit 2 (a run with cells) or bit 0 (a row settled cell by cell)
-            }
-            lat_any &= 5u;
-            while (__ballot(und != 0)) {                            // rare: a run end within rounding distance of its circle
-                if (und) {
-                    const int b = __ffs(und) - 1; und &= und - 1;
-                    const int k = -7 + (sub - 1) + 3 * (b >> 1);
-                    if (b & 1) lat_row_exact<false>(P, tab, A.vb, k, A.ub, 4, lat_cols, lat_rows, px, py, gxe, gye, nullptr, occ_e, cov_e);
-                    else lat_row_exact<true>(P, tab, A.vb, k, A.ub, 7, lat_cols, lat_rows, px, py, gxe, gye, mrow, nullptr, nullptr);
+                for (int t = 0; t < nrows; ++t) {
+                    const int k = kfirst + 2 * t;
+                    const unsigned r = lat_row(P, A, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e);
+                    und |= (r & 3u) << (2 * t);
+                    lat_any |= r;                                   // bit 2 (a run with cells) or bit 0 (a row settled cell by cell)
                 }
-            }
-            if (sub == 3) {
-                double sq = __builtin_inf(); int iq = 0x7FFFFFFF;
+                lat_any &= 5u;
+                while (__ballot(und != 0)) {                        // rare: a run end within rounding distance of its circle
+                    if (und) {
+                        const int b = __ffs(und) - 1; und &= und - 1;
+                        const int k = kfirst + 2 * (b >> 1);
+                        if (b & 1) lat_row_exact<false>(P, tab, A.vb, k, A.ub, 4, lat_cols, lat_rows, px, py, gxe, gye, nullptr, occ_e, cov_e);
+                        else lat_row_exact<true>(P, tab, A.vb, k, A.ub, 7, lat_cols, lat_rows, px, py, gxe, gye, mrow, nullptr, nullptr);
+                    }
+                }
+            } else {
+                // ---- nearest cell (CPP:863-913), in-shape flag, target block ----
+                // The four sites around the agent, exactly.  A site that is none of the four is at least one lattice
+                // pitch away in one coordinate, so once one of the four holds a cell closer than 0.99 pitches no other
+                // cell can be nearer (or as near): such an agent -- inside its shape or at its rim -- needs no screen.
+                double best = __builtin_inf(); int imin = 0x7FFFFFFF;
                 if (A.inr) {
                     const int du = A.fu < 0.f ? -1 : 1, dw = A.fv < 0.f ? -1 : 1;
-                    lat_site_exact(tab, A.ub, A.vb, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
-                    lat_site_exact(tab, A.ub + du, A.vb, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
-                    lat_site_exact(tab, A.ub, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
-                    lat_site_exact(tab, A.ub + du, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, sq, iq);
+                    lat_site_exact(tab, A.ub, A.vb, lat_cols, lat_rows, px, py, gxe, gye, best, imin);
+                    lat_site_exact(tab, A.ub + du, A.vb, lat_cols, lat_rows, px, py, gxe, gye, best, imin);
+                    lat_site_exact(tab, A.ub, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, best, imin);
+                    lat_site_exact(tab, A.ub + du, A.vb + dw, lat_cols, lat_rows, px, py, gxe, gye, best, imin);
                 }
-                unsigned *qs = reinterpret_cast<unsigned *>(L.rpart);                   // free until P6
-                qs[l] = (unsigned)__double2loint(sq); qs[64 + l] = (unsigned)__double2hiint(sq); qs[128 + l] = (unsigned)iq;
-            }
-        }
-        {
-        // nearest-cell screen over the compacted boundary cells: per 32-cell word the smallest s32 (as in the pass
-        // over all cells below); which cell it is is settled in P4
-        const int nbw = ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5;
-        const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
-        const float *bxe = lat_cbx + es * ASM_LAT_NB, *bye = lat_cby + es * ASM_LAT_NB;
-        for (int w = (sub + T - 1) & (T - 1); w < nbw; w += T) {    // wave 0, busy with the k-NN pass, takes the last share
-            unsigned k1 = 0xFFFFFFFFu;
-            const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
-            const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
+                const bool scr = active && !(best < 0.98 * (l_cell * l_cell));
+                if (__ballot(scr)) {
+                    // screen of the compacted boundary cells: per 32-cell word the smallest s32; candidates are the cells
+                    // within two units of 32 ulps of the overall smallest (the screen is off by a few ulps), compared in
+                    // double in ascending cell index with a strict '<': the reference's first minimum (CPP:889)
+                    const int nbw = ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5;    // wave-uniform
+                    const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
+                    const float *bxe = lat_cbx + es * ASM_LAT_NB, *bye = lat_cby + es * ASM_LAT_NB;
+                    const unsigned short *lat_bl = reinterpret_cast<const unsigned short *>(tab + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
+                    // one word at a time: its smallest s32, the two smallest of those over all words and the first word
+                    // that holds the smallest
+                    auto word_key = [&](int w) {
+                        unsigned k1 = 0xFFFFFFFFu;
+                        const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
+                        const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 x4 = X[q], y4 = Y[q];
-                const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
-                const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
-                const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
-                const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
-                k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
-                k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 x4 = X[q], y4 = Y[q];
+                            const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                            const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                            const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                            const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                            k1 = umin3(k1, __float_as_uint(sa.x), __float_as_uint(sa.y));
+                            k1 = umin3(k1, __float_as_uint(sb.x), __float_as_uint(sb.y));
+                        }
+                        return k1;
+                    };
+                    unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0;
+#pragma unroll 1
+                    for (int w = 0; w < nbw; ++w) {
+                        const unsigned k1 = word_key(w);
+                        if (k1 < G1) G1w = (unsigned)w;             // strict: the first word holding the smallest s32
+                        G2 = umed3(G1, G2, k1);
+                        G1 = G1 < k1 ? G1 : k1;
+                    }
+                    const unsigned lo = G1 >> 5, lim = (lo << 5) + 64u;     // candidate <=> bits(s32) < lim
+                    unsigned minw = 1u << G1w;
+                    if (__ballot(scr && !((G2 >> 5) - lo >= 2u))) {         // rare: another word's minimum is that close
+#pragma unroll 1
+                        for (int w = 0; w < nbw; ++w) if ((word_key(w) >> 5) - lo < 2u) minw |= 1u << w;
+                    }
+                    minw = scr ? minw : 0u;
+                    double bs = __builtin_inf(); int bi = 0x7FFFFFFF;
+                    while (minw) {
+                        const int w = __ffs(minw) - 1; minw &= minw - 1;
+                        const float4 *X = reinterpret_cast<const float4 *>(bxe + w * 32);
+                        const float4 *Y = reinterpret_cast<const float4 *>(bye + w * 32);
+                        unsigned cand = 0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 x4 = X[q], y4 = Y[q];
+                            const f32x2 xa = {x4.x, x4.y}, xb = {x4.z, x4.w}, ya = {y4.x, y4.y}, yb = {y4.z, y4.w};
+                            const f32x2 rxa = xa - p2x, rxb = xb - p2x, rya = ya - p2y, ryb = yb - p2y;
+                            const f32x2 sa = __builtin_elementwise_fma(rya, rya, rxa * rxa);
+                            const f32x2 sb = __builtin_elementwise_fma(ryb, ryb, rxb * rxb);
+                            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.x) - lim, 31);
+                            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sa.y) - lim, 31);
+                            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.x) - lim, 31);
+                            cand = __builtin_amdgcn_alignbit(cand, __float_as_uint(sb.y) - lim, 31);
+                        }
+                        cand = __brev(cand);
+                        while (cand) {
+                            const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
+                            const double dx = (double)bxe[c] - px, dy = (double)bye[c] - py;
+                            const double sd = dx * dx + dy * dy;
+                            if (sd < bs) { bs = sd; bi = (int)lat_bl[c]; }      // the list ascends in cell index
+                        }
+                    }
+                    // smaller distance wins, equal distances go to the lower cell index
+                    if (bs < best || (bs == best && bi < imin)) { best = bs; imin = bi; }
+                }
+                if (active) {
+                    imin = imin == 0x7FFFFFFF ? 0 : imin;
+                    const double dmin3 = sqrt(best);
+                    const bool in_flag = dmin3 < sqrt(2.0) * l_cell / 2;    // CPP:894
+                    L.fin[l] = (unsigned)imin | (in_flag ? 0x80000000u : 0u);   // imin < 1024
+                    inflag_w[la] = in_flag ? 1 : 0;                         // CPP:139
+                    nearest_w[la] = imin;
+                    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
+                    if (!in_flag) { t0 = gxe[imin] - pxf; t1 = gye[imin] - pyf; t2 = 0.f - L.vx[l]; t3 = 0.f - L.vy[l]; }
+                    const int tb = P.obs_dim - (2 + cap) * 2;               // CPP:304
+                    ostore(tb + 0, t0); ostore(tb + 1, t1);
+                    ostore(tb + 2, t2); ostore(tb + 3, t3);
+                    dmin_lat = dmin3;
+                } else {
+                    L.fin[l] = 0;
+                }
+                L.fin[64 + l] = 0;                                  // list lengths of the sparse compaction (P5); empty lists stay 0
+                if (P.want_stats) stats_target(dmin_lat);
             }
-            lat_wkey[(size_t)l * (ASM_LAT_NB / 32) + w] = k1;
-            if (k1 < G1) G1w = (unsigned)w;
-            G2 = umed3(G1, G2, k1);
-            G1 = G1 < k1 ? G1 : k1;
+        } else if (P.want_stats) {
+            stats_neighbours(nn_min, contacts);
         }
+        if (sub == 1 || sub == 2) {
+            const unsigned long long any = __ballot(lat_any != 0);
+            if (l == 0) { L.anyf[(sub - 1) * 2] = (unsigned)any; L.anyf[(sub - 1) * 2 + 1] = (unsigned)(any >> 32); }
         }
-        L.part[sub * 64 + l] = make_uint4(G1, G2, G1w, lat_any);
     } else {
         // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest
         // s32 is tracked (two cells per v_min3_u32); which cell it belongs to, and whether another cell is too
@@ -651,8 +778,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     STAMP(12);
     EXIT_AT(3);
 
-    // ---- P4 (wave 0): nearest cell, in-shape flag, target block -------------------------
+    // ---- P4 (wave 0; all-cells path only -- on the lattice path the fourth wave has done this in P3) ----
+    // nearest cell, in-shape flag, target block
     double dmin = 0.0;
+    if constexpr (!LAT) {
     if (sub == 0) {
         unsigned G1 = 0xFFFFFFFFu, G2 = 0xFFFFFFFFu, G1w = 0, ambw = 0;
 #pragma unroll
@@ -662,7 +791,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const unsigned t = G1 > q.x ? G1 : q.x, m = G2 < q.y ? G2 : q.y;
             G2 = m < t ? m : t;
             G1 = G1 < q.x ? G1 : q.x;
-            if constexpr (!LAT) ambw |= q.w;                        // lattice path: that field says whether the wave found sensed cells
+            ambw |= q.w;
         }
         int imin = 0;
         double smin = __builtin_inf();
@@ -673,20 +802,16 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             // evaluated in double; ascending index + strict '<' gives the reference's first minimum (CPP:889).
             const unsigned lo = G1 >> 5;
             unsigned minw = 1u << G1w;
-            // lattice path: the words are those of the compacted boundary list
-            const int nwords = LAT ? ((lat_nb0 > lat_nb1 ? lat_nb0 : lat_nb1) + 31) >> 5 : W;
-            const float *cxe = LAT ? lat_cbx + es * ASM_LAT_NB : gxe, *cye = LAT ? lat_cby + es * ASM_LAT_NB : gye;
-            [[maybe_unused]] const unsigned short *lat_bl = reinterpret_cast<const unsigned short *>(lat_tabs + es * LAT_TAB_BYTES + 8 * ASM_LAT_ROWS * ASM_LAT_CHUNKS);
             if (!((G2 >> 5) - lo >= 2u)) {
-                const unsigned *wkey = LAT ? lat_wkey + (size_t)l * (ASM_LAT_NB / 32) : reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
-                for (int w = 0; w < nwords; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
+                const unsigned *wkey = reinterpret_cast<const unsigned *>(L.sel) + (size_t)l * MW;
+                for (int w = 0; w < W; ++w) if ((wkey[w] >> 5) - lo < 2u) minw |= 1u << w;
             }
             const unsigned lim = (lo << 5) + 64u;                   // candidate <=> bits(s32) < lim
             const f32x2 p2x = {pxf, pxf}, p2y = {pyf, pyf};
             while (minw) {
                 const int w = __ffs(minw) - 1; minw &= minw - 1;
-                const float4 *X = reinterpret_cast<const float4 *>(cxe + w * 32);
-                const float4 *Y = reinterpret_cast<const float4 *>(cye + w * 32);
+                const float4 *X = reinterpret_cast<const float4 *>(gxe + w * 32);
+                const float4 *Y = reinterpret_cast<const float4 *>(gye + w * 32);
                 unsigned cand = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -703,18 +828,10 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
                 cand = __brev(cand);
                 while (cand) {
                     const int c = w * 32 + __ffs(cand) - 1; cand &= cand - 1;
-                    const double dx = (double)cxe[c] - px, dy = (double)cye[c] - py;
+                    const double dx = (double)gxe[c] - px, dy = (double)gye[c] - py;
                     const double sd = dx * dx + dy * dy;
-                    if (sd < smin) { smin = sd; imin = LAT ? (int)lat_bl[c] : c; }   // ascending cell index either way
+                    if (sd < smin) { smin = sd; imin = c; }         // ascending cell index
                 }
-            }
-            if constexpr (LAT) {
-                // the four lattice sites around the agent (wave 3, P3): smaller distance wins, equal distances go to the
-                // lower cell index (the reference's first minimum, CPP:889)
-                const unsigned *qs = reinterpret_cast<const unsigned *>(L.rpart);
-                const double sq = __hiloint2double((int)qs[64 + l], (int)qs[l]);
-                const int iq = (int)qs[128 + l];
-                if (sq < smin || (sq == smin && iq < imin)) { smin = sq; imin = iq; }
             }
             if (ambw) {
                 // Rare: sensed bits within the margin of T_sen, decided in double
@@ -738,9 +855,9 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             }
             dmin = sqrt(smin);
             const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;     // CPP:894
-            L.fin[l] = (unsigned)imin | ((unsigned)contacts << 16) | (in_flag ? 0x80000000u : 0u);   // imin < 1024, contacts < 32
-            inflag_g[(size_t)e * n_a + i] = in_flag ? 1 : 0;        // CPP:139
-            nearest_g[(size_t)e * n_a + i] = imin;
+            L.fin[l] = (unsigned)imin | (in_flag ? 0x80000000u : 0u);   // imin < 1024
+            inflag_w[la] = in_flag ? 1 : 0;                         // CPP:139
+            nearest_w[la] = imin;
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;           // CPP:141-142, 896-901 (x - x == 0)
             if (!in_flag) { t0 = gxe[imin] - pxf; t1 = gye[imin] - pyf; t2 = 0.f - L.vx[l]; t3 = 0.f - L.vy[l]; }
             const int tb = P.obs_dim - (2 + cap) * 2;               // CPP:304
@@ -749,12 +866,14 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         } else {
             L.fin[l] = 0;
         }
-        if constexpr (LAT) L.fin[64 + l] = 0;                       // list lengths of the sparse compaction (P5); empty lists stay 0
         if (T > 1 && P.want_stats)                                  // wave 1 computes the formation statistics in P7
-            L.part[l] = make_uint4(__double2loint(dmin), __double2hiint(dmin), __double2loint(nn_min), __double2hiint(nn_min));
+            L.part[l] = make_uint4((unsigned)contacts, 0u, (unsigned)__double2loint(nn_min), (unsigned)__double2hiint(nn_min));
+        if (T > 1 && P.want_stats)
+            L.part[(T - 1) * 64 + l] = make_uint4((unsigned)__double2loint(dmin), (unsigned)__double2hiint(dmin), 0u, 0u);
     }
     STAMP(13);
     __syncthreads();
+    }
     STAMP(14);
     EXIT_AT(4);
 
@@ -772,7 +891,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
     bool sparse = false;
     [[maybe_unused]] unsigned long long nzm = 0;
     if constexpr (LAT) {
-        nzm = __ballot((L.part[64 + l].w | L.part[128 + l].w | L.part[192 + l].w) != 0);
+        nzm = (unsigned long long)(L.anyf[0] | L.anyf[2]) | ((unsigned long long)(L.anyf[1] | L.anyf[3]) << 32);
         sparse = __popcll(nzm) <= ASM_SPARSE_MAX;
     }
     if (sparse) {
@@ -1123,7 +1242,7 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
         }
         if (active) {
             if (in_flag && !collision && uniform) reward += 1.0;    // CPP:559-561
-            if (P.want_reward) rew_g[(size_t)e * n_a + i] = (float)reward;
+            if (P.want_reward) rew_w[la] = (float)reward;
         }
         STAMP(8);
         if (P.want_stats) {                                         // TRAIN:128-131: reward sums, agents inside
@@ -1131,42 +1250,27 @@ __global__ __launch_bounds__(64 * T, ASM_FAST_MINW) void k_step_fast(DevParams P
             const double rs = (double)__popcll(__ballot(active && reward > 0.0) & half), rq = rs;     // rewards are 0 or 1
             const double inn = (double)__popcll(__ballot(active && in_flag) & half);
             if (i == 0 && env_ok) {
-                double *st = stats_g + (size_t)e * 8;
+                double *st = stats_g + (size_t)e0 * 8 + es * 8;
                 stat_add(&st[0], rs); stat_add(&st[1], rq); stat_add(&st[7], inn);
             }
         }
     }
-    // Formation statistics (TRAIN:132-135; WRAP:48-165): they do not depend on the reward, so with several waves the
-    // second one computes them while the first evaluates the reward (its inputs were handed over through LDS in P4).
+    // Formation statistics: they do not depend on the reward, so with several waves the second one adds them while the first
+    // evaluates the reward (all-cells path: their inputs were handed over through LDS in P4; lattice path: only the coverage
+    // is left, the other two pieces were added in P3 by the waves that computed their inputs).
     if (sub == SUB_PRIOR && P.want_stats) {
-        double dm = dmin, nn = nn_min; int cn = contacts;
-        if (T > 1) {
-            const uint4 q = L.part[l];
-            dm = __hiloint2double((int)q.y, (int)q.x); nn = __hiloint2double((int)q.w, (int)q.z);
-            cn = (int)((fin >> 16) & 0xFFu);
-        }
-        if (active && nn == 0.0) {                                  // an agent at this very position: WRAP:93-94 drops exact zeros
-            nn = __builtin_inf();
-#pragma nounroll
-            for (int j = 0; j < n_a; ++j) {
-                const double ex = (double)L.px[es * 32 + j] - px, ey = (double)L.py[es * 32 + j] - py, su = ex * ex + ey * ey;
-                if (su != 0 && su < nn) nn = su;
+        if constexpr (LAT) {
+            stats_coverage();
+        } else {
+            double dm = dmin, nn = nn_min; int cn = contacts;
+            if (T > 1) {
+                const uint4 q = L.part[l], q3 = L.part[(T - 1) * 64 + l];
+                dm = __hiloint2double((int)q3.y, (int)q3.x); nn = __hiloint2double((int)q.w, (int)q.z);
+                cn = (int)q.x;
             }
-        }
-        const double m = active ? sqrt(nn) : 0.0;
-        int ci = cn + (i < W ? __popc(cov_e[i]) << 16 : 0);                                           // two small sums in one word
-#pragma unroll
-        for (int mm = 16; mm >= 1; mm >>= 1) ci += __shfl_xor(ci, mm, 32);
-        const double cp = (double)(ci & 0xFFFF), covered = (double)(ci >> 16);
-        const double ds = half_sum(active ? dm : 0.0), ms = half_sum(m);
-        const double lo = half_min(active ? m : __builtin_inf()), hi = half_max(active ? m : -__builtin_inf());
-        const double mean = ms / n_a, dv = active ? m - mean : 0.0;
-        const double var = half_sum(dv * dv) / n_a;
-        if (i == 0 && env_ok) {
-            double *st = stats_g + (size_t)e * 8;
-            stat_add(&st[2], n_g > 0 ? covered / n_g : 0.0);          // WRAP:70; an environment without cells covers nothing
-            stat_add(&st[3], (var - lo) / (hi - lo));               // WRAP:98-99
-            stat_add(&st[4], cp); stat_add(&st[5], ds / n_a); stat_add(&st[6], 1.0);
+            stats_neighbours(nn, cn);
+            stats_target(dm);
+            stats_coverage();
         }
     }
     STAMP(9);
