@@ -22,6 +22,8 @@
 // indices as the reference; values are rounded once to S on output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <algorithm>
 
 #include "asm_kernels.h"
 
@@ -102,7 +104,9 @@ static int launch_step_fast_t(const DevParams &P, const LatArgs &lat, float *p, 
                               float *rew, float *prior, int *sensed, int *occupied, double *stats, hipStream_t st)
 {
     // three instantiations: the index-list outputs are compiled in only where they are asked for
-    const unsigned lds = P.lat ? P.fast_lds_bytes_lat : P.fast_lds_bytes;
+    // MARL_AMD_LDS_PAD (measurement knob): extra bytes of dynamic LDS per workgroup, to find where a CU stops taking one more workgroup
+    static const unsigned lds_pad = [] { const char *v = std::getenv("MARL_AMD_LDS_PAD"); return v ? (unsigned)std::atoi(v) : 0u; }();
+    const unsigned lds = (P.lat ? P.fast_lds_bytes_lat : P.fast_lds_bytes) + lds_pad;
     auto go = [&](auto kernel) {
         if (int rc = set_lds(kernel, lds)) return rc;
         hipLaunchKernelGGL(kernel, dim3((P.E + 1) / 2), dim3(64 * T), lds, st, P, lat, p, dp, act, grid, n_g,
