@@ -329,6 +329,13 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
 int asm_replay_draw_indices(uint64_t seed, uint32_t counter, const uint32_t *counter_dev /*nullable*/, int64_t lo,
                             int64_t hi, int N, int64_t *index, void *stream);
 
+/* Observation frames in the layout the reference hands its networks: rows[e][i][r] = obs[e][r][i], i.e. one row of
+ * obs_dim floats per agent (maddpg.py:84 transposes the (obs_dim, n_a) frame for the policy, train_assembly.py:119-120;
+ * buffer_agent.py:95-117 stores agent rows).  obs: [E][obs_dim][n_a] as the step writes it, rows: [E][n_a][obs_dim];
+ * both device memory, float32.  A tiled transpose through LDS at copy speed: PyTorch's strided copy of the same
+ * view takes 3.5 times as long at 4096 x 30 agents. */
+int asm_obs_rows_f32(int E, int n_a, int obs_dim, const float *obs, float *rows, void *stream);
+
 /* Rollout inference of the policy network for every agent of every environment, on the matrix cores (bf16 operands, fp32
  * accumulation): what MADDPG.step -> DDPGAgent.step -> MLPNetwork.forward compute one environment at a time
  * (maddpg.py:72-87, agents.py:69-96 without the exploration noise, networks.py:33-44: Linear - leaky_relu three times,

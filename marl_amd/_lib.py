@@ -48,7 +48,7 @@ EXPORTS = ["_get_observation", "_get_reward", "_sf_b2b_all", "_get_dist_b2w", "c
            "asm_batch_random_actions_f32", "asm_batch_metrics_f64", "asm_batch_rule_actions_f32", "asm_replay_gather_f32", "asm_replay_draw_indices",
            "asm_debug_sqrt_f64", "asm_debug_cos_f32_max_err", "asm_get_observation_noalloc", "asm_lattice_build",
            "asm_batch_check_lattice", "asm_set_step_schedule", "asm_debug_step_schedule",
-           "asm_policy_mlp_forward_bf16", "asm_policy_mlp_act_bf16"]
+           "asm_policy_mlp_forward_bf16", "asm_policy_mlp_act_bf16", "asm_obs_rows_f32"]
 
 _lib = None
 
@@ -109,6 +109,8 @@ def load() -> C.CDLL:
     lib.asm_policy_mlp_forward_bf16.argtypes = [i32] * 5 + [vp] * 8
     lib.asm_policy_mlp_act_bf16.restype = C.c_int
     lib.asm_policy_mlp_act_bf16.argtypes = [i32] * 5 + [vp] * 7 + [C.c_float, C.c_float, u64, u32, i64, vp]
+    lib.asm_obs_rows_f32.restype = C.c_int
+    lib.asm_obs_rows_f32.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.asm_set_step_schedule.restype = None
     lib.asm_set_step_schedule.argtypes = [C.c_int]
     if lib.asm_abi_version() != ABI_VERSION:

@@ -569,6 +569,14 @@ int asm_replay_gather_f32(int E, int n_a, int obs_dim, int episode_length, const
     return rc ? hip_fail(rc, "asm_replay_gather_f32") : 0;
 }
 
+int asm_obs_rows_f32(int E, int n_a, int obs_dim, const float *obs, float *rows, void *stream)
+{
+    if (E < 1 || n_a < 1 || obs_dim < 1 || !obs || !rows) return fail(1, "asm_obs_rows_f32: bad arguments");
+    if ((size_t)obs_dim * 33 * sizeof(float) > 160 * 1024) return fail(1, "asm_obs_rows_f32: obs_dim = %d: a tile does not fit the LDS", obs_dim);
+    int rc = asmenv::launch_obs_rows(E, n_a, obs_dim, obs, rows, (hipStream_t)stream);
+    return rc ? hip_fail(rc, "asm_obs_rows_f32") : 0;
+}
+
 int asm_policy_mlp_act_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1,
                             const void *w2, const void *w3, const void *w4, const float *bias, float *act, float noise_scale,
                             float epsilon, uint64_t seed, uint32_t step, int64_t env0, void *stream)

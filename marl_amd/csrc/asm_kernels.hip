@@ -235,6 +235,16 @@ int launch_replay_gather(int E, int n_a, int obs_dim, int T, const float *obs_ri
     return 0;
 }
 
+int launch_obs_rows(int E, int n_a, int obs_dim, const float *obs, float *rows, hipStream_t st)
+{
+    const int tiles = (n_a + ASM_ROWS_TILE - 1) / ASM_ROWS_TILE;
+    const size_t lds = (size_t)obs_dim * 33 * sizeof(float);
+    if (int rc = set_lds(k_obs_rows, lds)) return rc;
+    hipLaunchKernelGGL(k_obs_rows, dim3((unsigned)E * tiles), dim3(256), lds, st, n_a, obs_dim, tiles, obs, rows);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1, const void *w2,
                       const void *w3, const void *w4, const float *bias, float *act, float noise_scale, float epsilon,
                       uint64_t seed, uint32_t step, int64_t env0, hipStream_t st)

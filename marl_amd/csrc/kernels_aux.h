@@ -54,6 +54,28 @@ __global__ void k_replay_gather(int E, int n_a, int obs_dim, int T, const float 
     if (lane == 2) rew_out[k] = rew_ring[(size_t)q * n_a + i];
 }
 
+// Observation frames as the policy network reads them (maddpg.py:84 `observations.t()`, train_assembly.py:119):
+// rows[e][i][r] = obs[e][r][i].  One workgroup per (environment, block of 32 agents): the block's [obs_dim][32]
+// tile goes through LDS, read as 128-byte row pieces and written as whole agent rows (obs_dim contiguous floats).
+#define ASM_ROWS_TILE 32
+__global__ __launch_bounds__(256) void k_obs_rows(int n_a, int obs_dim, int tiles, const float *obs, float *rows)
+{
+    extern __shared__ float tile[];                                 // [obs_dim][33]: the odd stride keeps the column reads off one bank
+    const int e = blockIdx.x / tiles, i0 = (blockIdx.x - e * tiles) * ASM_ROWS_TILE;
+    const int ni = n_a - i0 < ASM_ROWS_TILE ? n_a - i0 : ASM_ROWS_TILE;
+    const float *src = obs + (size_t)e * obs_dim * n_a + i0;
+    for (int k = threadIdx.x; k < obs_dim * ASM_ROWS_TILE; k += 256) {
+        const int r = k >> 5, c = k & 31;
+        if (c < ni) tile[r * 33 + c] = src[(size_t)r * n_a + c];
+    }
+    __syncthreads();
+    float *dst = rows + ((size_t)e * n_a + i0) * obs_dim;           // the block's agents are consecutive rows: one contiguous run
+    for (int k = threadIdx.x; k < ni * obs_dim; k += 256) {
+        const int c = k / obs_dim, r = k - c * obs_dim;
+        dst[k] = tile[r * 33 + c];
+    }
+}
+
 // The 'rule' expert of ENV:525-596 for every agent of every environment, on the state the last observation was
 // taken of (its in-shape flags, nearest cells and sensed lists are inputs): entering velocity towards the nearest
 // cell when outside the shape, exploration velocity = 15 x the psi-weighted mean offset of the listed cells,

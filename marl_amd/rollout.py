@@ -95,6 +95,7 @@ class DDPGLearner:
         self._cri_grads = _FlatGrads(self.critic) if self.data_parallel else None
         self.gamma, self.tau = gamma, tau
         self.act_dtype = act_dtype                                         # rollout inference precision; None = float32
+        self._row_bufs = {}                                                # agent-major copies of the observation frames (act)
         self.niter = 0
         # bf16 rollouts on a HIP device go through the library's matrix-core kernel (marl_amd/policy_kernel.py) when the
         # network has a shape it takes; the weights are re-packed after every update
@@ -126,7 +127,7 @@ class DDPGLearner:
         if self.fused_policy is not None and obs.is_contiguous():
             a = self._fused(obs, torch.empty_like(out)).transpose(1, 2)    # (E, n, act_dim), as below
         else:
-            x = obs.transpose(1, 2).reshape(E * n, d)                      # maddpg.py:84: observations.t()
+            x = self._agent_rows(obs)                                      # maddpg.py:84: observations.t()
             if self.act_dtype is not None:                                 # e.g. torch.bfloat16: MFMA inference for rollouts
                 with torch.autocast("cuda", dtype=self.act_dtype):
                     a = self.policy(x).float()
@@ -140,6 +141,21 @@ class DDPGLearner:
             a = torch.where(coin, torch.empty_like(a).uniform_(-1.0, 1.0, generator=generator), a)
         out.copy_(a.transpose(1, 2))
         return out
+
+    def _agent_rows(self, obs: torch.Tensor) -> torch.Tensor:
+        """(E, obs_dim, n_a) frames -> (E * n_a, obs_dim) rows, one per agent.  On the device through the library's tiled
+        transpose (asm_obs_rows_f32) into a buffer kept per shape; elsewhere a strided copy."""
+        E, d, n = obs.shape
+        if not (obs.is_cuda and obs.is_contiguous() and obs.dtype is torch.float32):
+            return obs.transpose(1, 2).reshape(E * n, d)
+        from . import _lib
+        key = (E, d, n, obs.device)
+        buf = self._row_bufs.get(key)
+        if buf is None:
+            buf = self._row_bufs[key] = torch.empty(E * n, d, dtype=torch.float32, device=obs.device)
+        _lib.check(_lib.load().asm_obs_rows_f32(E, n, d, obs.data_ptr(), buf.data_ptr(),
+                                                torch.cuda.current_stream(obs.device).cuda_stream), "asm_obs_rows_f32")
+        return buf
 
     def policy_changed(self) -> None:
         """Tell the learner that the policy's weights were changed by something Python did not see run (a replayed HIP

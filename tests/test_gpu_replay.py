@@ -147,3 +147,31 @@ def test_graphed_train_phase(torch_cuda):
     n0 = learner.niter
     g.run(num_updates=5)
     assert g.captured_len == len(rp) and learner.niter == n0 + 5
+
+
+@pytest.mark.parametrize("E,n_a,obs_dim", [(5, 30, 192), (3, 7, 188), (2, 100, 192), (2, 1024, 192), (1, 33, 12)])
+def test_agent_rows_equal_the_transposed_frames(torch_cuda, E, n_a, obs_dim):
+    """asm_obs_rows_f32: rows[e][i][r] == obs[e][r][i], bit for bit (maddpg.py:84, the frame transposed for the policy)."""
+    torch = torch_cuda
+    from marl_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(E * 1000 + n_a)
+    obs = torch.randn(E, obs_dim, n_a, device="cuda", generator=g)
+    rows = torch.full((E, n_a, obs_dim), float("nan"), device="cuda")
+    _lib.check(lib.asm_obs_rows_f32(E, n_a, obs_dim, obs.data_ptr(), rows.data_ptr(), torch.cuda.current_stream().cuda_stream), "rows")
+    assert torch.equal(rows, obs.transpose(1, 2).contiguous())
+
+
+def test_float32_act_uses_the_agent_rows(torch_cuda):
+    """DDPGLearner.act in float32 (the reference's precision, networks.py:22-44) equals the network applied to the
+    transposed frames, whichever way the rows were produced."""
+    torch = torch_cuda
+    from marl_amd.rollout import DDPGLearner
+    torch.manual_seed(3)
+    learner = DDPGLearner(192, hidden_dim=64)
+    obs = torch.randn(6, 192, 30, device="cuda")
+    out = torch.empty(6, 2, 30, device="cuda")
+    learner.act(obs, out)
+    with torch.no_grad():
+        want = learner.policy(obs.transpose(1, 2).reshape(180, 192)).view(6, 30, 2).transpose(1, 2)
+    assert torch.equal(out, want)

@@ -17,6 +17,9 @@ import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+if "--tunableop" in sys.argv:                                              # read by PyTorch when it loads
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/tunableop_results.csv")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
@@ -35,6 +38,9 @@ ap.add_argument("--graph", action="store_true", help="train phase as a replayed 
 ap.add_argument("--act-dtype", choices=["float32", "bfloat16"], default="float32", help="rollout inference precision")
 ap.add_argument("--shards", type=int, default=1, help="step the rank's environments as this many shards on streams of their own (StreamShards)")
 ap.add_argument("--no-fused", action="store_true", help="bf16 rollouts through PyTorch autocast instead of the library's matrix-core policy kernel")
+ap.add_argument("--strided-copy", action="store_true", help="float32 rollouts: agent rows by PyTorch's strided copy of the transposed frames "
+                "instead of the library's tiled transpose (the previous behaviour, for before / after lines)")
+ap.add_argument("--tunableop", action="store_true", help="PyTorch TunableOp: the GEMM kernels are chosen by timing at first use (float32 rollouts gain ~6 %)")
 a = ap.parse_args()
 
 world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,6 +70,8 @@ learner = DDPGLearner(env.obs_dim_agent, device=device, act_dtype=torch.bfloat16
                       data_parallel=world > 1, capturable=a.graph)
 if a.no_fused:
     learner.fused_policy = None
+if a.strided_copy:
+    learner._agent_rows = lambda obs: obs.transpose(1, 2).reshape(obs.shape[0] * obs.shape[2], obs.shape[1])
 graphed = None
 if a.graph:
     from marl_amd.rollout import GraphedTrainPhase
@@ -98,6 +106,9 @@ if rank == 0:
                     f"policy/critic MLP 256, 30 updates of {a.batch_size} per episode and rank, replay in HBM "
                     f"({a.slots} episode slots), rollout inference in {a.act_dtype}"
                     + (" (fused matrix-core kernel)" if learner.fused_policy is not None else "")
+                    + (" -- lower precision than the reference's float32 policy (networks.py:22-44), not comparable" if a.act_dtype != "float32" else "")
+                    + (", agent rows by PyTorch's strided copy" if a.strided_copy and a.act_dtype == "float32" else "")
+                    + (", GEMM kernels chosen by TunableOp" if a.tunableop else "")
                     + (f", {a.shards} shards per GPU on streams of their own" if a.shards > 1 else "")
                     + (", learner replicas with averaged gradients" if world > 1 else "")
                     + (", train phase replayed from a HIP graph" if a.graph else ""),
