@@ -136,6 +136,9 @@ class DeviceReplay:
         self.slot, self.t = -1, 0
         self.complete = [False] * self.S                            # per slot: holds one whole episode
         self.seed, self.draws = int(seed), 0
+        # the complete slots, in order, as a device table the index draw renumbers through: kept up to date here, outside
+        # any HIP graph that captured a draw, so a replayed draw always lands in slots that hold whole episodes
+        self._slot_table = torch.zeros(self.S, dtype=torch.int64, device=dev)
 
     # ---- writing ---------------------------------------------------------------------
     def begin_episode(self) -> None:
@@ -145,6 +148,7 @@ class DeviceReplay:
         self.slot = (self.slot + 1) % self.S
         self.t = 0
         self.complete[self.slot] = False
+        self._refresh_slot_table()
         self.env.obs = self.obs_ring[self.slot, 0]
 
     def action_slot(self) -> torch.Tensor:
@@ -164,6 +168,12 @@ class DeviceReplay:
         self.t += 1
         if self.t == self.T:
             self.complete[self.slot] = True
+            self._refresh_slot_table()
+
+    def _refresh_slot_table(self) -> None:
+        slots = [k for k in range(self.S) if self.complete[k]]
+        slots += [slots[-1] if slots else 0] * (self.S - len(slots))
+        self._slot_table.copy_(torch.tensor(slots, dtype=torch.int64))
 
     @property
     def filled_slots(self) -> int:
@@ -173,30 +183,55 @@ class DeviceReplay:
     @filled_slots.setter
     def filled_slots(self, n: int) -> None:                         # tests fill the rings by hand
         self.complete = [k < n for k in range(self.S)]
+        self._refresh_slot_table()
 
     def __len__(self) -> int:
         """Stored transitions (agent rows), as len(ReplayBufferAgent)."""
         return self.filled_slots * self.T * self.env.E * self.env.n_a
 
     # ---- sampling --------------------------------------------------------------------
-    def draw_indices(self, N: int, out: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """N transition ids, uniform over the complete slots (with replacement).  counter_dev: a device int32 word
-        added to the draw counter inside the kernel (for launches captured into a HIP graph: increment it between
-        replays); `out`: where to write the ids."""
+    def draw_indices(self, N: int, out: Optional[torch.Tensor] = None, counter_dev: Optional[torch.Tensor] = None,
+                     without_replacement: bool = False) -> torch.Tensor:
+        """N transition ids, uniform over the complete slots.  counter_dev: a device int32 word added to the draw
+        counter inside the kernel (for launches captured into a HIP graph: increment it between replays); `out`:
+        where to write the ids.  By default the ids are drawn with replacement (one launch, nothing read back).
+        without_replacement=True gives N distinct ids like buffer_agent.py:149-154 (np.random.choice(...,
+        replace=False)): duplicates within the batch are drawn again until none is left, which reads one flag back
+        per round and is therefore not for captured draws."""
         if len(self) == 0:
             raise RuntimeError("no completed episode to sample from")
+        if without_replacement and counter_dev is not None:
+            raise ValueError("a draw without replacement decides on the host: it cannot be captured into a HIP graph")
+        if without_replacement and N > len(self):
+            raise ValueError(f"cannot draw {N} distinct ids out of {len(self)}")      # np.random.choice raises as well
         idx = torch.empty(N, dtype=torch.int64, device=self.env.device) if out is None else out
-        with torch.cuda.device(self.env.device):
-            rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, _ptr(counter_dev), 0, len(self), N, _ptr(idx),
-                                                  self.env._stream())
-        _lib.check(rc, "asm_replay_draw_indices")
-        self.draws += 1
+
+        def draw(dst):
+            with torch.cuda.device(self.env.device):
+                rc = self.lib.asm_replay_draw_indices(self.seed, self.draws, _ptr(counter_dev), 0, len(self), dst.numel(),
+                                                      _ptr(dst), self.env._stream())
+            _lib.check(rc, "asm_replay_draw_indices")
+            self.draws += 1
+
+        draw(idx)
+        if without_replacement:
+            while True:                                             # expected duplicates: N^2 / (2 len): ~0.1 per batch of 2048 out of 2.4e7
+                srt, order = torch.sort(idx)
+                dup = torch.zeros(N, dtype=torch.bool, device=idx.device)
+                dup[order[1:]] = srt[1:] == srt[:-1]                # every repeat after the first of its value
+                n_dup = int(dup.sum())
+                if n_dup == 0:
+                    break
+                fresh = torch.empty(n_dup, dtype=torch.int64, device=idx.device)
+                draw(fresh)
+                idx[dup] = fresh
         slots = [k for k in range(self.S) if self.complete[k]]
-        if slots != list(range(len(slots))):                        # a slot in between is being rewritten: renumber
+        if counter_dev is not None or slots != list(range(len(slots))):
+            # a slot in between is being rewritten: renumber through the table of complete slots (always, for a captured
+            # draw: the table is read when the graph is replayed)
             per_slot = self.T * self.env.E * self.env.n_a
-            table = torch.tensor(slots, dtype=torch.int64, device=idx.device)
-            remapped = table[idx // per_slot] * per_slot + idx % per_slot
-            idx = remapped if out is None else out.copy_(remapped)
+            remapped = self._slot_table[idx // per_slot] * per_slot + idx % per_slot
+            idx = idx.copy_(remapped)
         return idx
 
     def gather(self, idx: torch.Tensor, is_prior: bool = True, out=None):

@@ -172,11 +172,10 @@ class DDPGLearner:
         self._refresh_fused()
         return self.fused_policy.forward(obs, out)
 
-    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True,
-               branch_free: bool = False):
-        """maddpg.py:99-190.  Returns (critic loss, policy loss): Python floats, or 0-d tensors when
-        sync_losses=False (no host synchronisation inside the update loop).  branch_free: the mask of maddpg.py:162
-        is applied as a weight instead of an index selection, so no decision is taken on the host (graph capture)."""
+    # maddpg.py:99-190 in the pieces a data-parallel replica runs between its two gradient exchanges
+    # (maddpg.py:138-139, 179-180): critic loss + backward | critic step, policy loss + backward | policy step.
+    def critic_backward(self, obs, acs, rews, next_obs, dones):
+        """maddpg.py:120-136: the TD loss of the critic and its gradients.  Returns the loss (0-d tensor)."""
         if self.data_parallel:
             self._cri_grads.zero()
         else:
@@ -186,10 +185,11 @@ class DDPGLearner:
             target_value = rews + self.gamma * self.target_critic(trgt_in) * (1 - dones)
         vf_loss = F.mse_loss(self.critic(torch.cat((obs, acs), dim=1)), target_value)   # maddpg.py:130-134
         vf_loss.backward()
-        if self.data_parallel:
-            self._cri_grads.average(self.group)                            # maddpg.py:138-139
-        self.critic_optimizer.step()
+        return vf_loss.detach()
 
+    def policy_backward(self, obs, acs_prior=None, alpha: float = 0.5, branch_free: bool = False):
+        """maddpg.py:144-176 after the critic's step: -Q plus the prior regulariser, and the policy's gradients.
+        branch_free: the mask of maddpg.py:162 as a weight instead of an index selection (no decision on the host)."""
         if self.data_parallel:
             self._pol_grads.zero()
         else:
@@ -205,12 +205,29 @@ class DDPGLearner:
             elif valid.any():
                 pol_loss = pol_loss + 0.3 * alpha * F.mse_loss(pol[valid], acs_prior[valid])
         pol_loss.backward()
+        return pol_loss.detach()
+
+    def exchange_critic_grads(self) -> None:
+        if self.data_parallel:
+            self._cri_grads.average(self.group)                            # maddpg.py:138-139
+
+    def exchange_policy_grads(self) -> None:
         if self.data_parallel:
             self._pol_grads.average(self.group)                            # maddpg.py:179-180
+
+    def update(self, obs, acs, rews, next_obs, dones, acs_prior=None, alpha: float = 0.5, sync_losses: bool = True,
+               branch_free: bool = False):
+        """maddpg.py:99-190.  Returns (critic loss, policy loss): Python floats, or 0-d tensors when
+        sync_losses=False (no host synchronisation inside the update loop)."""
+        vf_loss = self.critic_backward(obs, acs, rews, next_obs, dones)
+        self.exchange_critic_grads()
+        self.critic_optimizer.step()
+        pol_loss = self.policy_backward(obs, acs_prior, alpha, branch_free)
+        self.exchange_policy_grads()
         self.policy_optimizer.step()
         if sync_losses:
-            return float(vf_loss.detach()), float(pol_loss.detach())
-        return vf_loss.detach(), pol_loss.detach()
+            return float(vf_loss), float(pol_loss)
+        return vf_loss, pol_loss
 
     @torch.no_grad()
     def update_all_targets(self):
@@ -318,54 +335,135 @@ def train_phase(env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceRep
     return losses
 
 
+class StagedUpdate:
+    """One DDPG update cut into the three pieces between which data-parallel replicas exchange gradients:
+
+        A  batch (batch_fn), critic loss + backward            -> all-reduce of the critic's flattened gradient
+        B  critic step, policy loss + backward                 -> all-reduce of the policy's flattened gradient
+        C  policy step, losses, soft target update, after_fn
+
+    On a HIP device the pieces are captured into HIP graphs -- one graph for a single-rank learner, three for
+    data-parallel replicas, the all-reduces issued eagerly between their replays, so nothing of the collective
+    library is ever captured -- and replayed per update.  Without graphs (use_graphs=False: CPU tests, gloo
+    rehearsals) the same pieces run eagerly in the same order.  batch_fn() -> (obs, acs, rews, next_obs, dones,
+    prior) must write into tensors that stay where they are between calls when graphs are used."""
+
+    def __init__(self, learner: DDPGLearner, batch_fn, alpha_fn, device, use_graphs: bool, after_fn=None):
+        if use_graphs and torch.device(device).type != "cuda":
+            raise RuntimeError("HIP graphs need a HIP device")
+        self.learner, self.batch_fn, self.alpha_fn, self.after_fn = learner, batch_fn, alpha_fn, after_fn
+        self.device, self.use_graphs = torch.device(device), bool(use_graphs)
+        self.losses = torch.zeros(2, dtype=torch.float32, device=device)
+        self.graphs = None
+        self._batch = None
+        self.launches_per_update = 0                                # graph replays + collectives of the last run (for the records)
+
+    # the three pieces
+    def _a(self):
+        self._batch = self.batch_fn()
+        obs, acs, rews, nxt, dones, _ = self._batch
+        self.losses[0].copy_(self.learner.critic_backward(obs, acs, rews, nxt, dones))
+
+    def _b(self):
+        self.learner.critic_optimizer.step()
+        obs, prior = self._batch[0], self._batch[5]
+        self.losses[1].copy_(self.learner.policy_backward(obs, prior, self.alpha_fn(), branch_free=True))
+
+    def _c(self):
+        self.learner.policy_optimizer.step()
+        self.learner.update_all_targets()
+        if self.after_fn is not None:
+            self.after_fn()
+
+    def _groups(self):
+        return [[self._a], [self._b], [self._c]] if self.learner.data_parallel else [[self._a, self._b, self._c]]
+
+    def _eager(self):
+        self._a(); self.learner.exchange_critic_grads()
+        self._b(); self.learner.exchange_policy_grads()
+        self._c()
+
+    def capture(self, warmup: int):
+        """Runs `warmup` updates eagerly (allocator, lazy optimiser state; they count as updates) and returns their
+        losses as a (warmup, 2) tensor; then records the pieces."""
+        out = torch.zeros(warmup, 2, dtype=torch.float32, device=self.device)
+        if not self.use_graphs:
+            for k in range(warmup):
+                self._eager(); out[k].copy_(self.losses)
+            self.graphs = []
+            return out
+        cur = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for k in range(warmup):
+                self._eager(); out[k].copy_(self.losses)
+        cur.wait_stream(side)
+        niter = self.learner.niter
+        self.graphs, pool = [], None
+        for group in self._groups():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, pool=pool):
+                for piece in group:
+                    piece()
+            pool = g.pool()                                         # the pieces share tensors: one memory pool for all graphs
+            self.graphs.append(g)
+        self.learner.niter = niter                                  # capturing ran nothing
+        return out
+
+    def run_once(self):
+        """One update; the losses are in self.losses afterwards."""
+        if not self.use_graphs:
+            self._eager()
+            self.launches_per_update = 0
+            return
+        exch = (self.learner.exchange_critic_grads, self.learner.exchange_policy_grads)
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            if len(self.graphs) > 1 and k < 2:
+                exch[k]()
+        self.learner.niter += 1
+        self.launches_per_update = len(self.graphs) + (2 if len(self.graphs) > 1 else 0)
+
+
 class GraphedTrainPhase:
-    """train_assembly.py:141-157 with one update (index draw, gather, DDPG update, soft target update) captured into a
-    HIP graph and replayed num_updates times: the update is a few dozen small kernels, and launched one by one from
+    """train_assembly.py:141-157 with one update (index draw, gather, DDPG update, soft target update) captured into
+    HIP graphs and replayed num_updates times: the update is a few dozen small kernels, and launched one by one from
     Python the 30 updates of an episode take longer than the 200 environment steps before them.
 
     The captured draw reads its counter from a device word that is incremented inside the graph, so every replay
-    samples new transitions.  The graph is re-captured when the number of stored transitions changes (the first
-    episodes, until the replay slots are full).  Needs optimisers built with capturable=True
-    (DDPGLearner(..., capturable=True)); losses come back as a (num_updates, 2) tensor without host round trips
-    in between.  Single-rank learners only (a collective cannot be captured with the gloo rehearsal backend)."""
+    samples new transitions; the table of complete episode slots it reads is a device tensor the replay keeps up to
+    date outside the graph.  The graphs are re-captured when the set of complete slots changes (the first episodes,
+    until the replay is full).  Needs optimisers built with capturable=True (DDPGLearner(..., capturable=True));
+    losses come back as a (num_updates, 2) tensor without host round trips in between.
+
+    Data-parallel replicas (DDPGLearner(data_parallel=True)): the update is cut at its two gradient exchanges into three
+    graphs, and the flattened all-reduces run eagerly between their replays (StagedUpdate) -- five launches per update
+    instead of one, nothing RCCL-specific captured."""
 
     def __init__(self, env: BatchedAssemblyEnv, learner: DDPGLearner, replay: DeviceReplay, batch_size: int = 2048):
-        if learner.data_parallel:
-            raise RuntimeError("GraphedTrainPhase captures a single-rank update")
         self.env, self.learner, self.replay, self.N = env, learner, replay, int(batch_size)
         dev = env.device
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.idx = torch.empty(self.N, dtype=torch.int64, device=dev)
         self.batch = None
-        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
-        self.graph, self.captured_len = None, -1
         self.is_prior = env.training_method == "llm_rl"
+        self.staged = StagedUpdate(learner, self._batch, lambda: self.env.alpha, dev, use_graphs=True,
+                                   after_fn=lambda: self.counter.add_(1))
+        self.captured_key = None
 
-    def _one_update(self):
+    @property
+    def losses(self):
+        return self.staged.losses
+
+    @property
+    def graph(self):                                                # (the first of the recorded graphs; None before the first run)
+        return self.staged.graphs[0] if self.staged.graphs else None
+
+    def _batch(self):
         self.replay.draw_indices(self.N, out=self.idx, counter_dev=self.counter)
         self.batch = self.replay.gather(self.idx, self.is_prior, out=self.batch)
-        obs, acs, rews, nxt, dones, prior = self.batch
-        vf, pl = self.learner.update(obs, acs, rews, nxt, dones, prior, self.env.alpha, sync_losses=False, branch_free=True)
-        self.losses[0].copy_(vf); self.losses[1].copy_(pl)
-        self.learner.update_all_targets()
-        self.counter.add_(1)
-
-    def _capture(self):
-        cur = torch.cuda.current_stream(self.env.device)
-        side = torch.cuda.Stream(device=self.env.device)
-        side.wait_stream(cur)
-        draws0 = self.replay.draws
-        with torch.cuda.stream(side):                               # warm-up outside the capture (allocator, lazy state of Adam)
-            for _ in range(3):
-                self._one_update()
-        cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self._one_update()
-        self.replay.draws = draws0 + 4
-        self.learner.niter -= 1                                     # capturing ran nothing
-        self.captured_len = len(self.replay)
-        return 3                                                    # updates the warm-up already did
+        return self.batch
 
     def run(self, num_updates=None):
         """Returns the (num_updates, 2) tensor of (critic loss, policy loss)."""
@@ -377,12 +475,15 @@ class GraphedTrainPhase:
             return torch.zeros(0, 2)
         out = torch.empty(num_updates, 2, dtype=torch.float32, device=self.env.device)
         done = 0
-        if self.graph is None or self.captured_len != len(self.replay):
-            done = min(self._capture(), num_updates)
-            out[:done] = self.losses
+        key = tuple(self.replay.complete)
+        if self.staged.graphs is None or self.captured_key != key:
+            done = min(3, num_updates)
+            draws0 = self.replay.draws
+            out[:done] = self.staged.capture(done)
+            self.replay.draws = draws0 + done + 1                   # the capture's own call of the draw ran nothing
+            self.captured_key = key
         for k in range(done, num_updates):
-            self.graph.replay()
-            out[k].copy_(self.losses)
-            self.learner.niter += 1
+            self.staged.run_once()
+            out[k].copy_(self.staged.losses)
         self.learner.policy_changed()                               # the replays moved the weights behind Python's back
         return out

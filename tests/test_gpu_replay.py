@@ -146,7 +146,7 @@ def test_graphed_train_phase(torch_cuda):
     run_episode(env, learner, rp, 6)                                # the replay grows: the graph is captured again
     n0 = learner.niter
     g.run(num_updates=5)
-    assert g.captured_len == len(rp) and learner.niter == n0 + 5
+    assert g.captured_key == tuple(rp.complete) and learner.niter == n0 + 5
 
 
 @pytest.mark.parametrize("E,n_a,obs_dim", [(5, 30, 192), (3, 7, 188), (2, 100, 192), (2, 1024, 192), (1, 33, 12)])
@@ -175,3 +175,22 @@ def test_float32_act_uses_the_agent_rows(torch_cuda):
     with torch.no_grad():
         want = learner.policy(obs.transpose(1, 2).reshape(180, 192)).view(6, 30, 2).transpose(1, 2)
     assert torch.equal(out, want)
+
+
+def test_draw_without_replacement_gives_distinct_ids(torch_cuda):
+    """buffer_agent.py:149-154 draws its batch with np.random.choice(..., replace=False): the optional mode of the
+    device draw returns N distinct ids of complete slots, down to N == every stored transition."""
+    torch = torch_cuda
+    from marl_amd.batched import BatchedAssemblyEnv
+    from marl_amd.replay import DeviceReplay
+    env = BatchedAssemblyEnv(3, 30)
+    rp = DeviceReplay(env, episode_length=20, slots=3)
+    rp.complete = [True, False, True]; rp._refresh_slot_table()       # 3600 stored rows, in slots 0 and 2
+    per_slot = 20 * 3 * 30
+    for N in (2048, 3600):                                            # a plain draw of 2048 out of 3600 repeats ~500 ids
+        idx = rp.draw_indices(N, without_replacement=True)
+        assert idx.numel() == N and torch.unique(idx).numel() == N
+        assert bool(((idx // per_slot == 0) | (idx // per_slot == 2)).all())
+    assert torch.unique(rp.draw_indices(2048)).numel() < 2048         # the default draws with replacement
+    with pytest.raises(ValueError):
+        rp.draw_indices(3601, without_replacement=True)

@@ -34,7 +34,7 @@ ap.add_argument("--episodes", type=int, default=3)
 ap.add_argument("--episode-length", type=int, default=200)
 ap.add_argument("--slots", type=int, default=2)
 ap.add_argument("--batch-size", type=int, default=2048)
-ap.add_argument("--graph", action="store_true", help="train phase as a replayed HIP graph (GraphedTrainPhase); single rank")
+ap.add_argument("--graph", action="store_true", help="train phase replayed from HIP graphs (GraphedTrainPhase): one graph per update, or three with the gradient all-reduces between them when the learner is data-parallel")
 ap.add_argument("--act-dtype", choices=["float32", "bfloat16"], default="float32", help="rollout inference precision")
 ap.add_argument("--shards", type=int, default=1, help="step the rank's environments as this many shards on streams of their own (StreamShards)")
 ap.add_argument("--no-fused", action="store_true", help="bf16 rollouts through PyTorch autocast instead of the library's matrix-core policy kernel")
