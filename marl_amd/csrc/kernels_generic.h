@@ -56,7 +56,10 @@ __device__ __forceinline__ void swarm_stats(const DevParams &P, double *part, in
 // fp32 and falls back to the exact double evaluation otherwise (cell_pass_fast above;
 // the neighbour and reward screens below follow the same rule), so its decisions are
 // those of the all-double code; S = double is the all-double code.
-template <typename S>
+// SW: compiled for the large swarm alone -- fp32 state, walls, Cartesian observation, the shapes' lattice description at hand,
+// cell lists for the pair passes, the whole environment in this workgroup -- so that the other schedules' code and registers
+// are not carried along (the launcher picks it exactly when all of that holds).
+template <typename S, bool SW = false>
 __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int e, int i, int row, int nthr, double l_cell,
                         const S *heading_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
                         int *sensed_g, int *occup_g, double *stats_g, int contact_pairs, const LatView *LV = nullptr)
@@ -67,7 +70,8 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     const int xat = g_exit_at;
 #endif
     // large swarms on fp32 state: pair loops screen 32 agents at a time, the cell pass settles undecided words only
-    const bool swarm = F32 && !P.periodic && P.SL >= 64;
+    const bool swarm = SW || (F32 && !P.periodic && P.SL >= 64);
+    const bool periodic = !SW && P.periodic, cartesian = SW || P.cartesian, split = !SW && P.parts > 1;
     const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
     const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
     S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
@@ -75,7 +79,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     [[maybe_unused]] BinView BVs;
     [[maybe_unused]] const BinView *BV = nullptr;
     if constexpr (F32) {
-        if (swarm && P.bins) {
+        if (SW || (swarm && P.bins)) {
             BVs = bins_carve(L.mask, P.bin_s, P.SL);
             bins_build(P, P.bin_s, BVs, row, nthr, P.n_a, reinterpret_cast<const float *>(L.px), reinterpret_cast<const float *>(L.py));
             BV = &BVs;
@@ -249,7 +253,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                         }
                 }
             }
-        } else if (F32 && !P.periodic) {
+        } else if (F32 && !periodic) {
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
             float nn32 = __builtin_inff(); int nnj = -1;
             for (int j = 0; j < n_a; ++j) {
@@ -267,7 +271,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             for (int j = 0; j < n_a; ++j) {
                 double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py; // CPP:84
                 if (P.want_stats) { double su = rx * rx + ry * ry; if (su != 0 && su < nn_min) nn_min = su; }
-                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
+                if (periodic) wrap_rel(rx, ry, P.half_w, P.half_h);        // CPP:93-95
                 const double s = rx * rx + ry * ry;                          // CPP:641
                 if (j != i && s < P.T_sen) consider(j, s);
             }
@@ -284,8 +288,8 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             double rx = 0, ry = 0, wx = 0, wy = 0;
             if (j >= 0) {
                 rx = (double)L.px[j] - px; ry = (double)L.py[j] - py;
-                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
-                if (P.cartesian) { wx = (double)L.vx[j] - vx; wy = (double)L.vy[j] - vy; }   // CPP:86
+                if (periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (cartesian) { wx = (double)L.vx[j] - vx; wy = (double)L.vy[j] - vy; }   // CPP:86
                 else {                                                                       // CPP:88
                     wx = (double)heading_g[j] - (double)heading_g[i];
                     wy = (double)heading_g[n_a + j] - (double)heading_g[n_a + i];
@@ -307,7 +311,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         bool done = false;
         if constexpr (F32) {
             if (swarm) {
-                if (LV)                                                  // the shapes' lattice description is at hand
+                if (SW || LV)                                            // the shapes' lattice description is at hand
                     imin = lat_cell_pass_lane(P, *LV, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)row * P.MW, L.occ, L.cov);
                 else
                     imin = cell_pass_words(P, active, L.px[i], L.py[i], L.gx, L.gy, L.mask + (size_t)row * P.MW,
@@ -321,7 +325,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if (!done) cell_pass<S, true>(P, true, px, py, L.gx, L.gy, row, L.mask, L.occ, L.cov, smin, imin);
     }
     if constexpr (F32) {
-        if (P.parts > 1 && LV)                                           // the other parts' agents: their occupancy / coverage bits
+        if (split && LV)                                           // the other parts' agents: their occupancy / coverage bits
             for (int a = row; a < n_a; a += nthr)
                 if (a != i) lat_occupancy_lane(P, *LV, L.px[a], L.py[a], L.gx, L.gy, L.occ, L.cov);
     }
@@ -350,10 +354,10 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         double t0, t1, t2, t3;
         if (in_flag) { t0 = px - px; t1 = py - py; t2 = vx - vx; t3 = vy - vy; }
         else { t0 = (double)L.gx[imin] - px; t1 = (double)L.gy[imin] - py; t2 = 0.0 - vx; t3 = 0.0 - vy; }
-        const int tb = P.cartesian ? P.obs_dim - (2 + P.n_obs) * 2 : P.obs_dim - 6;   // CPP:304, 317
+        const int tb = cartesian ? P.obs_dim - (2 + P.n_obs) * 2 : P.obs_dim - 6;   // CPP:304, 317
         ocol[(size_t)(tb + 0) * n_a] = (S)t0; ocol[(size_t)(tb + 1) * n_a] = (S)t1;
         ocol[(size_t)(tb + 2) * n_a] = (S)t2; ocol[(size_t)(tb + 3) * n_a] = (S)t3;
-        if (!P.cartesian) {                                              // CPP:322-324
+        if (!cartesian) {                                              // CPP:322-324
             ocol[(size_t)(tb + 4) * n_a] = heading_g[i]; ocol[(size_t)(tb + 5) * n_a] = heading_g[n_a + i];
         }
 
@@ -381,7 +385,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         BitIter it; it.init(mym, P.W, in_flag ? L.occ : nullptr, true);
         int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * P.n_obs : nullptr;
         const int gb = P.obs_dim - P.n_obs * 2;
-        const bool cart = P.cartesian != 0;
+        const bool cart = cartesian != 0;
         const bool rew_on = in_flag && P.want_reward;
         if constexpr (F32) {
             // values: fl32(cell - p) is the correctly rounded difference either way; reward
@@ -486,7 +490,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             int j = j6[q];
             if (j >= 0) {
                 double rx = (double)L.px[j] - px, ry = (double)L.py[j] - py;
-                if (P.periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
+                if (periodic) wrap_rel(rx, ry, P.half_w, P.half_h);
                 if (rx * rx + ry * ry < P.T_ravoid) collision = true;    // CPP:487 r_avoid > norm
             }
         }
@@ -502,7 +506,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     STAMP(8);
     EXIT_AT(7);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
-    if (P.want_stats && P.parts > 1) {
+    if (P.want_stats && split) {
         // an environment split over several workgroups: the statistics come from a launch of their own (k_swarm_stats);
         // the covered cells (WRAP:48-72) are counted here, by the first part, from the whole environment's bitmap
         if (P.part == 0 && row == 0 && e < P.E) {
@@ -587,13 +591,15 @@ __global__ void k_observe(DevParams P, const S *p_g, const S *dp_g, const S *hea
 }
 
 // ENV:482-661: forces + prior on the old state, integration, observation + reward.
-template <typename S>
+template <typename S, bool SW = false>     // SW: the large-swarm specialisation (see observe)
 __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *act_g, const S *grid_g, const int *ng_g,
                        const double *lcell_g, int *nbr_g, int *inflag_g, int *nearest_g, S *obs_g, S *rew_g,
                        S *prior_g, int *sensed_g, int *occup_g, double *stats_g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int es = threadIdx.x / P.SL, i = threadIdx.x % P.SL, e = blockIdx.x * P.EPB + es;
+    static_assert(!SW || sizeof(S) == 4, "the large-swarm specialisation is single precision");
+    const int es = SW ? 0 : threadIdx.x / P.SL, i = SW ? (int)threadIdx.x : threadIdx.x % P.SL, e = SW ? (int)blockIdx.x : blockIdx.x * P.EPB + es;
+    const bool periodic = !SW && P.periodic, lat2 = SW || P.lat == 2;
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a;
     EnvLds<S> L = carve<S>(smem, P, es);
@@ -605,7 +611,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     const int ng_r = ng_g[e_c];
     const double l_cell_r = lcell_g[e_c];
     [[maybe_unused]] int sid_r = 0;
-    if constexpr (sizeof(S) == 4) { if (P.lat == 2) sid_r = lat.shape_id[e_c]; }
+    if constexpr (sizeof(S) == 4) { if (lat2) sid_r = lat.shape_id[e_c]; }
     const int n_g = env_ok ? clamp_ng(ng_r, P.n_g_max) : 0;
     const double l_cell = env_ok ? l_cell_r : 1.0;
     load_env<S>(P, L, env_ok, active, e, i, n_g, p_g, dp_g, grid_g);
@@ -616,7 +622,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     LatView LV;
     [[maybe_unused]] int lat_sid = 0;
     if constexpr (sizeof(S) == 4) {
-        if (P.lat == 2) {
+        if (lat2) {
             lat_sid = env_ok ? sid_r : 0;
             lat_sid = lat_sid < 0 ? 0 : (lat_sid >= lat.n_shapes ? lat.n_shapes - 1 : lat_sid);
             const asm_lattice_shape *sh = lat.shapes + lat_sid;
@@ -631,7 +637,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     STAMP(1);
     EXIT_AT(1);
     if constexpr (sizeof(S) == 4) {
-        if (P.lat == 2)
+        if (lat2)
             for (int k = i; k < ASM_LAT_NB; k += P.SL) {
                 float x = 1e30f, y = 1e30f;
                 if (k < LV.nb) { const int c = lat.shapes[lat_sid].boundary[k]; x = L.gx[c]; y = L.gy[c]; }
@@ -643,7 +649,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     [[maybe_unused]] BinView BC;
     [[maybe_unused]] bool use_bins = false;
     if constexpr (sizeof(S) == 4) {
-        if (!P.periodic && P.SL >= 64 && P.bins) {
+        if (SW || (!periodic && P.SL >= 64 && P.bins)) {
             BC = bins_carve(L.mask, P.bin_c, P.SL);
             bins_build(P, P.bin_c, BC, i, P.SL, P.n_a, reinterpret_cast<const float *>(L.px), reinterpret_cast<const float *>(L.py));
             use_bins = true;
@@ -663,7 +669,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
         const double px = (double)L.px[i], py = (double)L.py[i], vx = (double)L.vx[i], vy = (double)L.vy[i];
         // ---- ball-ball spring forces: ENV:437-452 + CPP:740-820, row sum in ascending k ----
         double fx = 0.0, fy = 0.0;
-        if (sizeof(S) == 4 && !P.periodic && P.SL >= 64) {                       // large swarm
+        if (SW || (sizeof(S) == 4 && !periodic && P.SL >= 64)) {                 // large swarm
             if constexpr (sizeof(S) == 4) {
                 const float pxf = L.px[i], pyf = L.py[i];
                 // With a cell list: the agents that pass the single-precision screen are gathered from the bins
@@ -720,7 +726,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
             if (k == i) continue;
             if (sizeof(S) == 4) {                                                // fp32 screen: certain misses
                 const float fx32 = (float)L.px[k] - (float)L.px[i], fy32 = (float)L.py[k] - (float)L.py[i];
-                if (!(__builtin_fmaf(fy32, fy32, fx32 * fx32) < P.Tcontact_hi_f) && !(P.want_stats && P.periodic && i == 0)) continue;
+                if (!(__builtin_fmaf(fy32, fy32, fx32 * fx32) < P.Tcontact_hi_f) && !(P.want_stats && periodic && i == 0)) continue;
             }
             double dx = (double)L.px[k] - px, dy = (double)L.py[k] - py;         // CPP:782-785 (delta = p_k - p_i)
             double s = dx * dx + dy * dy;                                        // ENV:444 (no wrap for rows >= 1)
@@ -730,7 +736,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
                 fx += 1.0 * gap * P.k_ball * (-(dx / d));                        // CPP:790-793
                 fy += 1.0 * gap * P.k_ball * (-(dy / d));
                 if (k > i) ++contacts;
-            } else if (P.want_stats && P.periodic && i == 0) {
+            } else if (P.want_stats && periodic && i == 0) {
                 // ENV:442-443: only agent 0's row of the distance matrix is wrapped; it is
                 // never read by the force loop but is counted by WRAP:131-145.
                 double wx = dx, wy = dy; wrap_rel(wx, wy, P.half_w, P.half_h);
@@ -739,7 +745,7 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
         }
         // ---- walls: CPP:822-860, ENV:510-513 ----
         double wfx = 0.0, wfy = 0.0, dfx = 0.0, dfy = 0.0;
-        if (!P.periodic) {
+        if (!periodic) {
             const double r = P.size_a;
             double d0 = px - r - (-P.half_w);                                    // CPP:841 (boundary_pos[0] = -half_w)
             double d1 = P.half_h - (py + r);                                     // CPP:842
@@ -778,12 +784,12 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
         double ux = (double)(sens * act_xr);                                     // ENV:627,633 (1 * float32)
         double uy = (double)(sens * act_yr);
         double Fx = ux + fx, Fy = uy + fy;
-        if (!P.periodic) { Fx = Fx + wfx + dfx; Fy = Fy + wfy + dfy; }           // ENV:633
+        if (!periodic) { Fx = Fx + wfx + dfx; Fy = Fy + wfy + dfy; }           // ENV:633
         nvx = vx + (Fx / P.mass) * P.dt; nvy = vy + (Fy / P.mass) * P.dt;        // ENV:638-641
         nvx = fmin(fmax(nvx, -P.vel_max), P.vel_max);                            // ENV:642
         nvy = fmin(fmax(nvy, -P.vel_max), P.vel_max);
         npx = px + nvx * P.dt; npy = py + nvy * P.dt;                            // ENV:645
-        if (P.periodic) {                                                        // ENV:646-647, 778-781
+        if (periodic) {                                                        // ENV:646-647, 778-781
             if (npx < -P.half_w) npx += 2 * P.half_w;
             if (npx > P.half_w) npx -= 2 * P.half_w;
             if (npy < -P.half_h) npy += 2 * P.half_h;
@@ -804,13 +810,13 @@ __global__ void k_step(DevParams P, LatArgs lat, S *p_g, S *dp_g, const float *a
     __syncthreads();
     STAMP(3);
     EXIT_AT(2);
-    if (P.parts > 1) {                                               // the observation of the new state is the part launch's
+    if (!SW && P.parts > 1) {                                        // the observation of the new state is the part launch's
         if (P.want_stats && i == 0 && env_ok) stats_g[(size_t)e * 8 + 4] += (double)*L.cnt;
         return;
     }
     DevParams Q = P; Q.n_g_e = n_g;
-    observe<S>(Q, L, active, e, i, i, P.SL, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
-               stats_g, -1, (sizeof(S) == 4 && P.lat == 2) ? &LV : nullptr);
+    observe<S, SW>(Q, L, active, e, i, i, P.SL, l_cell, nullptr, nbr_g, inflag_g, nearest_g, obs_g, rew_g, sensed_g, occup_g,
+                   stats_g, -1, (sizeof(S) == 4 && lat2) ? &LV : nullptr);
 }
 
 // Observation + reward of the state in p_g / dp_g for large swarms on the lattice path, an environment split over
