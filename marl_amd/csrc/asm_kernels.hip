@@ -152,7 +152,8 @@ int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float
     if constexpr (sizeof(S) == 4) {
         // the large swarm's own instantiation: walls, lattice description, cell lists, the whole environment in one workgroup
         static const bool off = std::getenv("MARL_AMD_NO_SWARM_KERNEL") != nullptr;      // measurement knob: the generic instantiation
-        if (P.lat == 2 && P.bins && P.parts <= 1 && !P.periodic && P.EPB == 1 && P.cartesian && !off) {
+        if (P.lat == 2 && P.bins && P.parts <= 1 && !P.periodic && P.EPB == 1 && P.cartesian && P.W <= 32 && P.n_obs >= 2 &&
+            (P.n_obs & 1) == 0 && !off) {
             if (int rc = set_lds(k_step<S, true>, P.lds_block_bytes)) return rc;
             hipLaunchKernelGGL((k_step<S, true>), dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, lat, p, dp, act, grid, n_g, l_cell,
                                nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);

@@ -333,6 +333,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     EXIT_AT(4);
     const double dmin = sqrt(smin);
     const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
+    if constexpr (SW) { if (row == 0) L.cnt[1] = 0; }                    // length of the emission's queue of lists to reduce
     __syncthreads();
 
     unsigned *mym = L.mask + (size_t)row * P.MW;
@@ -381,6 +382,168 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     };
     double num0 = 0.0, num1 = 0.0, den = 0.0;
     bool uniform = false, uniform_known = false;
+    [[maybe_unused]] bool exact_by_wave = false, exact_in_order = false;
+    auto exact_sums = [&]() {                                            // CPP:515-539 in the reference's order (in-shape agents: rew_on)
+        num0 = 0.0; num1 = 0.0; den = 0.0;
+        BitIter it2; it2.init(mym, P.W, L.occ, true);
+        emit_list(it2, n_after, P.n_obs, [&](int, int cell) {
+            if (cell >= 0) {
+                const double gx = (double)L.gx[cell] - px, gy = (double)L.gy[cell] - py;
+                const double psi = psi_exact(gx, gy);
+                num0 += psi * gx; num1 += psi * gy; den += psi;
+            }
+        });
+    };
+    if constexpr (SW) {
+        // Large swarm (W <= 32 words, even cap: checked where the kernel is picked).
+        const int lane = threadIdx.x & 63, cap = P.n_obs, gb = P.obs_dim - cap * 2;
+        // A sub-sampled list (n > cap, CPP:246-251) is first reduced, in its row of LDS, to the cells it keeps; after that
+        // every list is "slot k = k-th cell" and one loop without data-dependent branches serves all lanes.  (A lane that
+        // sub-samples inside the slot loop makes its whole wave take the list bits one at a time, and with a few such lanes
+        // in most workgroups the others wait for that wave at the next barrier.)  Slot k keeps the cell of rank
+        // round(k (n - 1) / (cap - 1)) = floor((2 k (n - 1) + cap - 1) / (2 (cap - 1))): cap - 1 is odd, so the quotient is
+        // never half-way and the reference's double arithmetic rounds to the same side.  A wave reduces one list at a
+        // time, a lane per byte of the list's bit words: ranks by a prefix sum of the bytes' popcounts, then the cell of
+        // rank r stays iff some k has r D <= k inc + cap - 1 < (r + 1) D (inc = 2 (n - 1), D = 2 (cap - 1); inc > D, so
+        // there is at most one), i.e. iff k = ceil((r D - cap + 1) / inc) satisfies the right-hand bound and k < cap.
+        // The lists to reduce are few and unevenly spread (most waves have none, some eight), so they are queued in the
+        // velocity rows of LDS, which nothing reads after the agent block, and dealt out over the workgroup's waves.
+        unsigned *q_meta = reinterpret_cast<unsigned *>(L.vx), *q_nz = reinterpret_cast<unsigned *>(L.vy);
+        const bool subs = active && n_after > cap;
+        const unsigned long long mb = __ballot(subs);
+        int qidx = 0;
+        if (mb) {
+            int b0 = 0;
+            if (lane == 0) b0 = atomicAdd(L.cnt + 1, __popcll(mb));
+            qidx = __builtin_amdgcn_readfirstlane(b0) +
+                   (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0));
+            if (subs) q_meta[qidx] = (unsigned)row | ((unsigned)n_after << 10) | (in_flag ? 1u << 21 : 0u);
+        }
+        __syncthreads();                                                 // (also: every lane is through with its occupied list)
+        const int n_queued = L.cnt[1];
+        for (int item = __builtin_amdgcn_readfirstlane(row >> 6); item < n_queued; item += nthr >> 6) {
+            const unsigned meta = q_meta[item];
+            const int row_s = (int)(meta & 1023u), n_s = (int)((meta >> 10) & 2047u);
+            const unsigned occ_s = (meta >> 21) ? 0xFFFFFFFFu : 0u;      // CPP:155
+            unsigned *ms = L.mask + (size_t)row_s * P.MW;
+            const int D = 2 * (cap - 1), inc = 2 * (n_s - 1);
+            const float rinc = 1.0f / (float)inc;
+            int base = 0;
+            unsigned nz_s = 0;
+            for (int t0 = 0; t0 < 4 * P.W; t0 += 64) {
+                const int t = t0 + lane;
+                const bool in = t < 4 * P.W;
+                const int w = in ? t >> 2 : 0, q8 = (t & 3) * 8;
+                unsigned sub = in ? ((ms[w] & ~(L.occ[w] & occ_s)) >> q8) & 0xFFu : 0u;
+                const int cnt = __popc(sub);
+                int incl = cnt;
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { const int o = __shfl_up(incl, m, 64); incl += lane >= m ? o : 0; }
+                int r = base + incl - cnt;
+                base += __builtin_amdgcn_readlane(incl, 63);
+                unsigned keep = 0;
+                while (sub) {
+                    const unsigned bit = sub & (0u - sub); sub ^= bit;
+                    const int A = r * D - (cap - 1);
+                    int k = (int)__builtin_ceilf((float)A * rinc);       // within one of ceil(A / inc): all integers below 2^24
+                    k = k < 0 ? 0 : k;
+                    if (k * inc < A) ++k; else if (k > 0 && (k - 1) * inc >= A) --k;
+                    if (k < cap && k * inc + (cap - 1) < (r + 1) * D) keep |= bit;
+                    ++r;
+                }
+                if (in) reinterpret_cast<unsigned char *>(ms)[t] = (unsigned char)keep;   // (every lane has read its word by now)
+                const unsigned long long kb = __ballot(keep != 0);
+                for (int j = 0; j < 16; ++j) nz_s |= ((kb >> (4 * j)) & 0xFull) ? 1u << ((t0 >> 2) + j) : 0u;
+            }
+            if (lane == 0) q_nz[item] = nz_s;
+        }
+        __syncthreads();
+        if (subs) { nz = q_nz[qidx]; n_after = cap; }
+        if (active) {
+            const bool rew_on = in_flag && P.want_reward;
+            const int n_out = n_after < cap ? n_after : cap;
+            const float pxf = (float)L.px[i], pyf = (float)L.py[i];
+            int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * cap : nullptr;
+            float fn0 = 0.f, fn1 = 0.f, fden = 0.f;
+            // The cell block's rows go out as buffer stores: resource = the environment's observation block, vector offset =
+            // the lane's column, scalar offset = the row, so a row store needs no vector address arithmetic; non-temporal,
+            // as the rows of a large swarm are written once and read by a later kernel.
+            const __amdgpu_buffer_rsrc_t obs_rs =
+                __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
+            // (the row offset is the same in every lane; said explicitly, or it lands in a vector register and every store
+            // becomes a loop over the distinct values of that register)
+            const int row_bytes = __builtin_amdgcn_readfirstlane(n_a * 4), gb_bytes = __builtin_amdgcn_readfirstlane(gb * n_a * 4);
+            auto ostore = [&](int r, float v) {                          // r: row within the cell block
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, i * 4,
+                                                      __builtin_amdgcn_readfirstlane(gb_bytes + r * row_bytes), 2);
+            };
+            // Four slots per trip: their cells are taken off the lane's bit words first (a lane's next non-empty word is
+            // fetched one word ahead, so running out of bits costs a register move, not an LDS round trip), then the eight
+            // coordinate reads go out together, then the arithmetic and the eight row stores.  The only branches are uniform
+            // across the wave (a lane needs its next word; the wave has no reward term; the lists of all lanes are through).
+            constexpr int RB = 4;
+            const bool any_rew = __ballot(rew_on) != 0;
+            auto fetch = [&](unsigned &fb, int &fw) {                    // the lane's next non-empty word (none: no bits)
+                const int w = __ffs(nz) - 1;                             // -1 when none is left
+                nz &= nz - 1;
+                const int wc = w < 0 ? 0 : w;
+                const unsigned f = mym[wc] & ~(L.occ[wc] & occm);
+                fb = w < 0 ? 0u : f; fw = wc * 32;
+            };
+            unsigned bits, nbits; int wbase, nwbase;
+            fetch(bits, wbase); fetch(nbits, nwbase);
+            for (int k0 = 0; k0 < cap; k0 += RB) {                       // (k0 stays in a scalar register)
+                if (__ballot(k0 < n_out) == 0) {                         // the lists of all lanes are through: zeros (CPP:279-296)
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (k0 + q < cap) { ostore(2 * (k0 + q), 0.f); ostore(2 * (k0 + q) + 1, 0.f); if (sdst) sdst[k0 + q] = -1; }
+                    continue;
+                }
+                int cell[RB]; bool need[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    need[q] = k0 + q < n_out;
+                    const bool refill = need[q] && bits == 0;
+                    if (__ballot(refill)) {
+                        if (refill) { bits = nbits; wbase = nwbase; fetch(nbits, nwbase); }
+                    }
+                    cell[q] = need[q] ? wbase + __ffs(bits) - 1 : 0;     // bits != 0 where need
+                    bits = need[q] ? bits & (bits - 1) : bits;
+                }
+                float gx[RB], gy[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) { gx[q] = (float)L.gx[cell[q]]; gy[q] = (float)L.gy[cell[q]]; }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int k = k0 + q;
+                    if (k < cap) {
+                        float rx = gx[q] - pxf, ry = gy[q] - pyf;        // CPP:285-286
+                        rx = need[q] ? rx : 0.f; ry = need[q] ? ry : 0.f;
+                        if (any_rew) {
+                            const float z = __builtin_amdgcn_sqrtf(__builtin_fmaf(ry, ry, rx * rx));
+                            float psi = 0.5f + 0.5f * __builtin_amdgcn_cosf(z * P.inv2dsen_f);          // cos(pi z / d_sen)
+                            psi = (rew_on && need[q]) ? psi : 0.f;
+                            fn0 = __builtin_fmaf(psi, rx, fn0); fn1 = __builtin_fmaf(psi, ry, fn1); fden += psi;
+                        }
+                        ostore(2 * k, rx); ostore(2 * k + 1, ry);
+                        if (sdst) sdst[k] = need[q] ? cell[q] : -1;
+                    }
+                }
+            }
+            if (rew_on && n_after > 0 && fden > 0.f) {
+                // Single-precision screen.  The weights psi carry an absolute error below 1e-6 (argument rounding
+                // 2*pi*1.5e-7, v_cos_f32 below 5e-7, halved, plus one rounding), every term and every accumulation
+                // step a relative rounding of 6e-8, so with n terms and |g| < d_sen
+                // |v32 - v| < 0.64 n (1e-6 / den + 6e-8) + 1e-7 for the norm v of the mean offset; doubled here.
+                const float rden = 1.0f / fden;
+                const float v0 = fn0 * rden, v1 = fn1 * rden;
+                const float vn = __builtin_amdgcn_sqrtf(__builtin_fmaf(v1, v1, v0 * v0));
+                const float margin = 1.28f * (float)n_out * __builtin_fmaf(1e-6f, rden, 6e-8f) + 2e-7f;
+                if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; uniform_known = true; }
+            }
+            if (rew_on && n_after > 0 && !uniform_known) exact_by_wave = true;   // borderline: the exact sums, by the wave below
+        }
+    } else
     if (active) {
         BitIter it; it.init(mym, P.W, in_flag ? L.occ : nullptr, true);
         int *sdst = sensed_g ? sensed_g + ((size_t)e * n_a + i) * P.n_obs : nullptr;
@@ -426,6 +589,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 // numerator is kept as a running sum; a lane takes one more bit whenever it passes the next multiple
                 // of the denominator (exactly once per slot when the list is not sub-sampled).
                 const int cap = P.n_obs, n_out = n_after < cap ? n_after : cap;
+                {
                 const int D = 2 * (cap - 1), inc = n_after > cap ? 2 * (n_after - 1) : D;
                 int acc = cap - 1 - inc, thr = 0;
                 unsigned bits = 0; int wbase = 0, cell = -1;
@@ -442,6 +606,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                     }
                     slot(k, k < n_out ? cell : -1);
                 }
+                }
             } else
             emit_list(it, n_after, P.n_obs, slot);
             if (rew_on && n_after > 0 && fden > 0.f) {
@@ -457,14 +622,11 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; uniform_known = true; }
             }
             if (rew_on && n_after > 0 && !uniform_known) {               // borderline: the exact sums
-                BitIter it2; it2.init(mym, P.W, L.occ, true);
-                emit_list(it2, n_after, P.n_obs, [&](int, int cell) {
-                    if (cell >= 0) {
-                        const double gx = (double)L.gx[cell] - px, gy = (double)L.gy[cell] - py;
-                        const double psi = psi_exact(gx, gy);
-                        num0 += psi * gx; num1 += psi * gy; den += psi;
-                    }
-                });
+                // A large swarm hands an agent whose list is not sub-sampled to its whole wave below (one lane walking 80
+                // cells through the double-precision cosine holds up the other 63, and its workgroup, for longer than the
+                // rest of the step takes); everybody else sums here, in the reference's order.
+                if (swarm && n_after <= P.n_obs) exact_by_wave = true;
+                else exact_in_order = true;
             }
         } else {
             emit_list(it, n_after, P.n_obs, [&](int k, int cell) {
@@ -479,6 +641,44 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         }
     }
 
+    if constexpr (F32) {
+        if (swarm) {
+            // Borderline agents of a large swarm: the reference's double-precision sums (CPP:515-552), one agent at a time
+            // with the 64 lanes of its wave sharing the bytes of its list's bit words.  The terms are the reference's; only
+            // their order of summation differs (relative error below 80 * 2^-53), so a result within 1e-11 of the threshold
+            // falls through to the sequential evaluation in the reference's order.
+            const int lane = threadIdx.x & 63;
+            for (unsigned long long todo = __ballot(exact_by_wave); todo; todo &= todo - 1) {
+                const int src = __ffsll(todo) - 1;
+                const int row_s = __builtin_amdgcn_readlane(row, src), i_s = __builtin_amdgcn_readlane(i, src);
+                const double sx = (double)L.px[i_s], sy = (double)L.py[i_s];
+                const unsigned *ms = L.mask + (size_t)row_s * P.MW;
+                double a0 = 0.0, a1 = 0.0, ad = 0.0;
+                for (int t = lane; t < 4 * P.W; t += 64) {
+                    const int w = t >> 2, q8 = (t & 3) * 8;
+                    unsigned sub = ((ms[w] & ~L.occ[w]) >> q8) & 0xFFu;  // (inside the shape: occupied cells are off the list, CPP:155)
+                    while (sub) {
+                        const int cell = w * 32 + q8 + __ffs(sub) - 1; sub &= sub - 1;
+                        const double gx = (double)L.gx[cell] - sx, gy = (double)L.gy[cell] - sy;
+                        const double psi = psi_exact(gx, gy);
+                        a0 += psi * gx; a1 += psi * gy; ad += psi;
+                    }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    a0 += __shfl_xor(a0, m, 64); a1 += __shfl_xor(a1, m, 64); ad += __shfl_xor(ad, m, 64);
+                }
+                if (lane == src) {
+                    if (ad == 0) ad = 1E-8;                              // CPP:542-544
+                    const double v0 = 1.0 * a0 / ad, v1 = 1.0 * a1 / ad; // CPP:547-548
+                    const double qq = v0 * v0 + v1 * v1;
+                    if (fabs(qq - P.T_v005) > 1e-11 * P.T_v005) { uniform = qq < P.T_v005; uniform_known = true; }   // CPP:550-552
+                    else exact_in_order = true;
+                }
+            }
+        }
+        if (exact_in_order) exact_sums();
+    }
     STAMP(7);
     EXIT_AT(6);
     // ---- reward: CPP:457-564 ----
@@ -504,6 +704,9 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
 
     STAMP(8);
+#ifdef ASM_DIAG
+    if constexpr (SW) { if (g_diag && (threadIdx.x & 63) == 0) g_diag[(size_t)blockIdx.x * 32 + 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter(); }
+#endif
     EXIT_AT(7);
     // ---- per-environment step statistics (TRAIN:128-135; WRAP:48-165) ----
     if (P.want_stats && split) {

@@ -80,8 +80,19 @@ if b[:, 25].any():
     t = (b[:, [0, 19, 27, 29, 30, 28, 25, 1]] - b[:, [26]]).astype(np.float64).mean(0)
     print("P0 of the first wave, cycles after its first instruction: first stamp %.0f | n_g there %.0f | grid loads issued %.0f | shape ids there %.0f | "
           "table loads issued %.0f | first grid data %.0f | at the barrier %.0f | barrier released %.0f" % tuple(t))
+if not b[:, 12].any() and b[:, 16:32].all():
+    # the large swarm's kernel: when each of the 16 waves reached the statistics barrier, relative to the first wave
+    rel = (b[:, 16:32].astype(np.float64) - b[:, [8]].astype(np.float64))
+    print("waves at the statistics barrier, cycles after the first wave got there: mean per wave",
+          [int(x) for x in rel.mean(0)], "| last wave: mean %.0f, p90 %.0f, max %.0f" % (
+              rel.max(1).mean(), np.percentile(rel.max(1), 90), rel.max()))
 slow = np.argsort(-wall)[:5]
 print("slowest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in slow])
+order = np.argsort(wall)
+mid = order[len(order) // 2 - 2:len(order) // 2 + 3]
+print("median workgroups (phase cycles): ", [(int(k), [int(x) for x in d[k]]) for k in mid])
+fast = order[:5]
+print("fastest workgroups (phase cycles):", [(int(k), [int(x) for x in d[k]]) for k in fast])
 names = ["load env -> LDS", "dynamics (forces, prior, integrate)", "contact count + state write", "k-NN + agent block",
          "cell pass", "in-flag, popcounts, target block", "sensed emission", "reward", "stats"]
 if b[:, 12].any():          # the multi-wave kernel stamps the same slots at its own phase boundaries (first wave's view)

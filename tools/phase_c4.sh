@@ -8,7 +8,7 @@ export MARL_AMD_LIB=$lib
 cd /tmp && export TMPDIR=/tmp
 for x in 1 2 3 4 5 6 7 0; do
   export MARL_AMD_DBG_EXIT=$x
-  out=$GRAFT_REPO_ROOT/gpurun_out/r02/c4_exit_$x; mkdir -p $out
+  out=$GRAFT_REPO_ROOT/gpurun_out/c4_exit_$x; mkdir -p $out
   echo "== exit $x"
   timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $out/pass1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 30 --warmup 5 --repeats 1 --envs-per-gpu 256 --agents 1024 --streams 1 "$@" > $out/pass1.log 2>&1 || { echo "pass failed"; tail -3 $out/pass1.log; exit 1; }
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out "k_step<"

@@ -1,23 +1,21 @@
-"""Per-phase differences of the counters printed by tools/phase_c4.sh / tools/phase_lds.sh (one `== exit k` block per
-phase boundary, exit 0 = the whole kernel last): python tools/phase_table.py <file> [name,name,...]"""
+"""Differences between consecutive 'exit' runs of tools/phase_valu.sh / tools/phase_c4.sh: the phases' own counts.
+
+    python tools/phase_table.py gpurun_out/r03/c4_phase_counts.txt
+"""
 import re
 import sys
 
-d, cur = {}, None
-for line in open(sys.argv[1]):
-    m = re.match(r"== exit (\d)", line)
-    if m:
-        cur = int(m.group(1)); d[cur] = {}
+t = open(sys.argv[1]).read()
+blocks = re.split(r"== exit (\d+)", t)[1:]
+names = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+prev = {}
+for k in range(0, len(blocks), 2):
+    x = int(blocks[k])
+    d = {m.group(1): float(m.group(2)) for m in re.finditer(r"(SQ_\w+)\s+launches=\d+ mean=\s*([\d.]+)", blocks[k + 1])}
+    if not d:
         continue
-    m = re.match(r"(\S+)\s+launches=\s*\d+ mean=\s*([\d.]+)", line)
-    if m and cur is not None:
-        d[cur][m.group(1)] = float(m.group(2))
-order = [k for k in d if k != 0] + [0]
-names = sys.argv[2].split(",") if len(sys.argv) > 2 else [f"to exit {k}" for k in order]
-cols = list(d[order[0]])
-print(f"{'phase':12s}" + "".join(f"{c[3:]:>18s}" for c in cols) + "   (millions per launch)")
-prev = {c: 0.0 for c in cols}
-for x, n in zip(order, names):
-    print(f"{n:12s}" + "".join(f"{(d[x][c] - prev[c]) / 1e6:18.2f}" for c in cols))
-    prev = d[x]
-print(f"{'total':12s}" + "".join(f"{d[0][c] / 1e6:18.2f}" for c in cols))
+    label = names[k // 2] if names and k // 2 < len(names) else f"up to exit {x}"
+    cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]
+    print(f"{label:28s} " + "  ".join(f"{c[3:]} {(d.get(c, 0) - prev.get(c, 0)) / 1e6:7.2f}M" for c in cols))
+    prev = d
+print(f"{'whole kernel':28s} " + "  ".join(f"{c[3:]} {prev.get(c, 0) / 1e6:7.2f}M" for c in cols))
