@@ -109,6 +109,7 @@ __device__ __forceinline__ double reward_weight(const DevParams &P, double z)
 #define ASM_FAST_MINW_LAT 5  // waves per SIMD the default lattice kernel is compiled for (96 registers; its LDS lets five workgroups share a CU)
 #endif
 #ifndef ASM_SPARSE_MAX
+#define ASM_LAT_ITEM_MAX 384 // lattice path: up to this many (agent, row) items per environment the rows are dealt out item by item
 #define ASM_SPARSE_MAX 64    // lattice path: up to this many sensing agents of a workgroup's 64, the lists are compacted agent by agent (64: always;
                              // measured as fast as the lane-by-lane loop even when every agent senses cells)
 #endif
@@ -282,8 +283,10 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
         }
         for (int w = tid; w < 4 * W; w += 64 * T) L.occ[w] = 0;
         if (sub == 0) { L.px[l] = sa; L.py[l] = sb; L.vx[l] = sc; L.vy[l] = sd; }
-        if constexpr (LAT)
+        if constexpr (LAT) {
             for (int w = tid; w < 64 * MW; w += 64 * T) L.mask[w] = 0;   // the sensed masks are built by OR-ing runs of cells
+            if (tid < 4) L.anyf[tid] = 0;
+        }
     }
 #ifdef ASM_DIAG
     if (g_diag && tid == 0) {                                       // first wave: its start, loads issued, first grid data there, arrival at the barrier
@@ -597,6 +600,57 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
                 A.bando = P.lat_cb * (float)Rod * invl_f + 4e-6f * A.Ro2;
             }
             const unsigned char *tab = lat_tabs + es * LAT_TAB_BYTES;
+            // The lattice rows an agent can touch at all: rows -7 .. 7 around its nearest site that exist in the shape's
+            // table, and none when the agent is out of reach of the bounding box.  Under random actions most agents are
+            // out of reach, so the two waves deal out (agent, row) items, one per lane and pass, instead of walking all
+            // 15 rows with every lane: per half-wave (one environment each) a prefix sum of the agents' row counts, a
+            // binary search of the lane's item number in it, then the row for that agent.  When the items would take more
+            // passes than the row loop has rows' worth of work (many agents inside their shape), the row loop runs.
+            int it_klo = 0, it_cnt = 0, it_incl = 0, it_n0 = 0, it_n1 = 0;
+            if (sub != 3) {
+                it_klo = -A.vb > -7 ? -A.vb : -7;
+                const int it_khi = lat_rows - 1 - A.vb < 7 ? lat_rows - 1 - A.vb : 7;
+                it_cnt = A.inr ? it_khi - it_klo + 1 : 0;
+                it_cnt = it_cnt < 0 ? 0 : it_cnt;
+                it_incl = it_cnt;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) { const int o = __shfl_up(it_incl, d, 32); it_incl += i >= d ? o : 0; }
+                it_n0 = __builtin_amdgcn_readlane(it_incl, 31); it_n1 = __builtin_amdgcn_readlane(it_incl, 63);
+            }
+            const int it_nmax = it_n0 > it_n1 ? it_n0 : it_n1;
+            const bool by_items = sub != 3 && it_nmax <= ASM_LAT_ITEM_MAX && 2 * 64 * P.capp + 32 >= 16 * ASM_LAT_NB + 1536;
+            if (by_items) {
+                // tables behind the compacted boundary coordinates, in the area of the slot lists (written after the next
+                // barrier); both waves write the same values, each reads after its own writes
+                int *t_incl = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(L.sel) + 16 * ASM_LAT_NB) + es * 32;
+                int *t_off = t_incl + 64;
+                uint4 *t_site = reinterpret_cast<uint4 *>(t_incl - es * 32 + 128) + es * 32;
+                t_incl[i] = it_incl; t_off[i] = it_klo - (it_incl - it_cnt);
+                t_site[i] = make_uint4((unsigned)A.ub, (unsigned)A.vb, __float_as_uint(A.fu), __float_as_uint(A.fv));
+                const int it_n = es ? it_n1 : it_n0;
+                for (int t0 = 0; t0 < it_nmax; t0 += 64) {
+                    const int t = t0 + (sub - 1) * 32 + i;
+                    const bool valid = t < it_n;
+                    int a = 0;
+#pragma unroll
+                    for (int step = 16; step >= 1; step >>= 1) a += t_incl[a + step - 1] <= t ? step : 0;   // agents whose items end at or before t
+                    const int k = t + t_off[a];
+                    const uint4 site = t_site[a];
+                    LatLane B = A;
+                    B.ub = (int)site.x; B.vb = (int)site.y; B.fu = __uint_as_float(site.z); B.fv = __uint_as_float(site.w);
+                    B.inr = valid;
+                    unsigned *mrow = L.mask + (size_t)(es * 32 + a) * MW;
+                    unsigned r = lat_row(P, B, tab, k, k >= -P.lat_KO && k <= P.lat_KO, lat_cols, lat_rows, mrow, occ_e, cov_e);
+                    if (r & 5u) atomicOr(&L.anyf[es], 1u << a);     // a run with cells, or a row settled cell by cell below
+                    while (__ballot((r & 3u) != 0)) {               // rare: a run end within rounding distance of its circle
+                        if (r & 3u) {
+                            const double pxa = (double)L.px[es * 32 + a], pya = (double)L.py[es * 32 + a];
+                            if (r & 1u) { lat_row_exact<true>(P, tab, B.vb, k, B.ub, 7, lat_cols, lat_rows, pxa, pya, gxe, gye, mrow, nullptr, nullptr); r &= ~1u; }
+                            else { lat_row_exact<false>(P, tab, B.vb, k, B.ub, 4, lat_cols, lat_rows, pxa, pya, gxe, gye, nullptr, occ_e, cov_e); r &= ~2u; }
+                        }
+                    }
+                }
+            } else
             if (sub != 3) {
                 unsigned *mrow = L.mask + (size_t)l * MW;
                 unsigned und = 0;                                   // bits 2t, 2t + 1: sensed / occupancy run of row t undecided
@@ -723,9 +777,9 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
         } else if (P.want_stats) {
             stats_neighbours(nn_min, contacts);
         }
-        if (sub == 1 || sub == 2) {
+        if (sub == 1 || sub == 2) {                                  // (the item passes OR their agents' bits into words 0 and 1)
             const unsigned long long any = __ballot(lat_any != 0);
-            if (l == 0) { L.anyf[(sub - 1) * 2] = (unsigned)any; L.anyf[(sub - 1) * 2 + 1] = (unsigned)(any >> 32); }
+            if (l == 0) { atomicOr(&L.anyf[(sub - 1) * 2], (unsigned)any); atomicOr(&L.anyf[(sub - 1) * 2 + 1], (unsigned)(any >> 32)); }
         }
     } else {
         // single-precision screening pass (see cell_pass_fast for the error argument).  Per word only the smallest

@@ -8,4 +8,5 @@ for x in 1 2 3 4 5 6 0 13; do
   export MARL_AMD_DBG_EXIT=$x
   echo "== exit $x"
   bash $GRAFT_REPO_ROOT/tools/pmc_ab.sh exits_$x $lib | grep -E "INSTS_VALU|INSTS_SALU|INSTS_LDS|pass failed" || exit 1
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/exits_$x            # the raw per-launch CSVs are large
 done
