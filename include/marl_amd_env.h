@@ -362,7 +362,8 @@ int asm_policy_mlp_act_bf16(int E, int n_a, int obs_dim, int hidden, int act_dim
 /* Self-test hook: which kernel asm_batch_step_f32 would launch for these arguments: waves per workgroup of the
  * multi-wave kernel (4, 2, 1) or 0 for the generic kernel, plus 16 if its lattice path is taken, plus 32 if the
  * generic kernel's (large swarms), plus 64 if the pair passes go through cell lists, plus 128 for the three-launch
- * step; negative on bad arguments.  Host-side only. */
+ * step, plus 256 when the large swarm's own instantiation of the generic kernel runs; negative on bad arguments.
+ * Host-side only. */
 int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lattice /*nullable*/);
 
 /* Self-test hook: out[k] = sqrt(in[k]) evaluated on the device in double (the

@@ -619,7 +619,7 @@ int asm_debug_step_schedule(const asm_params *prm, int E, const asm_lattice *lat
     else lattice_usable_swarm(lattice, prm, &P, &LA);
     DevParams part;
     const int split = !P.fast_T && split_usable(&P, &part) ? 1 : 0;
-    return P.fast_T + 16 * P.lat + 64 * P.bins + 128 * split;
+    return P.fast_T + 16 * P.lat + 64 * P.bins + 128 * split + 256 * (!P.fast_T && !split && asmenv::uses_swarm_kernel(P) ? 1 : 0);
 }
 
 #ifdef ASM_DIAG

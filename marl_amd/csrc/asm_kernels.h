@@ -99,6 +99,7 @@ int launch_rule_actions(const DevParams &P, const float *p, const float *dp, con
                         const int *inflags, const int *nearest, const int *sensed, float *act, hipStream_t st);
 int launch_metrics(int E, int n_a, int NGP, double r_avoid, double size_a, const float *p, const float *grid,
                    const int *n_g, double *out, hipStream_t st);
+bool uses_swarm_kernel(const DevParams &P);              // the step of these parameters runs k_step<float, true>
 int launch_obs_rows(int E, int n_a, int obs_dim, const float *obs, float *rows, hipStream_t st);
 int launch_policy_mlp(int E, int n_a, int obs_dim, int hidden, int act_dim, const float *obs, const void *w1, const void *w2,
                       const void *w3, const void *w4, const float *bias, float *act, float noise_scale, float epsilon,

@@ -140,6 +140,14 @@ int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp
     }
 }
 
+// The large swarm's own instantiation of the step kernel (k_step<float, true>) serves exactly these launches.
+bool uses_swarm_kernel(const DevParams &P)
+{
+    static const bool off = std::getenv("MARL_AMD_NO_SWARM_KERNEL") != nullptr;          // measurement knob: the generic instantiation
+    return P.lat == 2 && P.bins && P.parts <= 1 && !P.periodic && P.EPB == 1 && P.cartesian && P.W <= 32 && P.n_obs >= 2 &&
+           (P.n_obs & 1) == 0 && !off;
+}
+
 template <typename S>
 int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float *act, const S *grid, const int *n_g,
                 const double *l_cell, int *nbr, int *inflags, int *nearest, S *obs, S *rew, S *prior, int *sensed,
@@ -151,9 +159,7 @@ int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float
 #endif
     if constexpr (sizeof(S) == 4) {
         // the large swarm's own instantiation: walls, lattice description, cell lists, the whole environment in one workgroup
-        static const bool off = std::getenv("MARL_AMD_NO_SWARM_KERNEL") != nullptr;      // measurement knob: the generic instantiation
-        if (P.lat == 2 && P.bins && P.parts <= 1 && !P.periodic && P.EPB == 1 && P.cartesian && P.W <= 32 && P.n_obs >= 2 &&
-            (P.n_obs & 1) == 0 && !off) {
+        if (uses_swarm_kernel(P)) {
             if (int rc = set_lds(k_step<S, true>, P.lds_block_bytes)) return rc;
             hipLaunchKernelGGL((k_step<S, true>), dim3(P.grid), dim3(P.block), P.lds_block_bytes, st, P, lat, p, dp, act, grid, n_g, l_cell,
                                nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats);

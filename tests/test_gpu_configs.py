@@ -82,6 +82,9 @@ def test_config4_large_swarm_full_size(torch_cuda):
     sh.reset(); sh.synchronize()
     for tw in twins:
         tw.reset()
+    # the reset has placed the shapes, so their lattice description is in use: lattice path, cell lists, the large swarm's
+    # own instantiation of the generic kernel -- for the shards and for the twins
+    assert all(x.step_schedule() == 32 + 64 + 256 for x in list(sh.envs) + twins)
     want = np.zeros(8)
     for t in range(steps):
         acts = sh.on_each(lambda k, env: env.random_actions(step=t))

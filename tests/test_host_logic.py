@@ -158,13 +158,17 @@ def test_bench_roofline_inputs():
     assert bench.b_alg_per_agent_step(30, 500.0) == pytest.approx(872 + 8 * 500 / 30)
     assert bench.f_alg_per_agent_step(1024, 500.0) == pytest.approx(15 * 500 + 20 * 1023 + 2400)
     t = bench.measured_traffic(4096, 30, 2)
-    assert t is not None and t["source"] == "profiles/r02_pmc.json"
+    assert t is not None and t["source"] == "profiles/r03_pmc.json"
     assert t["hbm_bytes_per_launch"] > 0.9 * 2048 * 30 * bench.b_alg_per_agent_step(30, 511.8)
     assert bench.measured_traffic(4096, 31, 2) is None
-    assert bench.measured_traffic(256, 1024, 1)["source"] == "profiles/r02_c4_pmc.json"
-    lines = [json.load(open(os.path.join(REPO, "profiles", "r02_bench_default.json"))),
-             json.load(open(os.path.join(REPO, "profiles", "r02_bench_steps20_warmup5.json")))]
-    lines += [json.loads(l) for l in open(os.path.join(REPO, "profiles", "r02_bench_variants.jsonl"))]
+    assert bench.measured_traffic(256, 1024, 1)["source"] == "profiles/r03_c4_pmc.json"
+    assert bench.measured_traffic(256, 1024, 4)["source"] == "profiles/r03_c4_pmc.json"      # counter passes serialise the launches
+    assert bench.profiled_kernel(256, 1024, 4)["kernel"] == "asmenv::k_step<float, true>"
+    assert bench.step_kernel_name(32 + 64 + 256, False, 0, False).startswith("asmenv::k_step<float, true>")
+    assert bench.step_kernel_name(4 + 16, False, 0, False) == "asmenv::k_step_fast<4, false, 0, true, false>"
+    lines = [json.load(open(os.path.join(REPO, "profiles", "r03_bench_default.json"))),
+             json.load(open(os.path.join(REPO, "profiles", "r03_bench_steps20_warmup5.json")))]
+    lines += [json.loads(l) for l in open(os.path.join(REPO, "profiles", "r03_bench_variants.jsonl"))]
     for line in lines:
         r, c = line["roofline"], line["config"]
         per_gpu = line["value"] / line["n_gpus"]
@@ -179,7 +183,7 @@ def test_bench_roofline_inputs():
         assert line["timing"]["windows"] >= 5 and line["timing"]["steps_per_window"] == line["steps"]
         assert f'{c["agents"]}-agent' in line["metric"]
     # a 20-step run measures the same step time as the 2000-step run (both taken on one box, one after the other)
-    assert lines[1]["ms_per_step"] == pytest.approx(lines[0]["ms_per_step"], rel=0.03)
+    assert lines[1]["ms_per_step"] == pytest.approx(lines[0]["ms_per_step"], rel=0.05)
     assert lines[0]["cpu_baseline"]["kind"] in ("reference", "port") and lines[0]["cpu_baseline"]["cores"] >= 1
 
 

@@ -66,9 +66,15 @@ e_ = (b[:, 11] - b[:, 10].min()) / 100.0
 h, _ = np.histogram(e_, bins=np.arange(0, max(e_.max(), 1.0) + 4.0, 4.0))
 print("workgroup ends per 4 us:  ", h.tolist())
 if b[:, 12].any():
-    x = b[:, [5, 12, 13, 14, 6, 15, 7]].astype(np.float64)
-    dd = np.diff(x, axis=1)
-    print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f | barrier %.0f | emission %.0f" % tuple(dd.mean(0)))
+    if b[:, 13].all():
+        x = b[:, [5, 12, 13, 14, 6, 15, 7]].astype(np.float64)
+        dd = np.diff(x, axis=1)
+        print("fast kernel, cycles: barrier after cell pass %.0f | P4 %.0f | barrier %.0f | P5 scan %.0f | barrier %.0f | emission %.0f" % tuple(dd.mean(0)))
+    else:                                                   # lattice path: the nearest cell is settled inside P3 by the fourth wave
+        x = b[:, [5, 12, 14, 6, 15, 7]].astype(np.float64)
+        dd = np.diff(x, axis=1)
+        print("fast kernel (lattice path), first wave's cycles: waiting at the barrier that ends P3 %.0f | up to the list phase %.0f | P5 slot lists %.0f | "
+              "barrier %.0f | emission %.0f" % tuple(dd.mean(0)))
     if b[:, 16].any():
         print("P5 split: popcount pass %.0f | list loop %.0f cycles, %.1f iterations of thread 0 (max %d)" % (
             (b[:, 16] - b[:, 14]).mean(), (b[:, 6] - b[:, 16]).mean(), b[:, 17].mean(), b[:, 17].max()))

@@ -8,7 +8,7 @@ import sys
 t = open(sys.argv[1]).read()
 blocks = re.split(r"== exit (\d+)", t)[1:]
 names = sys.argv[2].split(",") if len(sys.argv) > 2 else None
-prev = {}
+prev, whole = {}, {}
 for k in range(0, len(blocks), 2):
     x = int(blocks[k])
     d = {m.group(1): float(m.group(2)) for m in re.finditer(r"(SQ_\w+)\s+launches=\d+ mean=\s*([\d.]+)", blocks[k + 1])}
@@ -18,4 +18,6 @@ for k in range(0, len(blocks), 2):
     cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"]
     print(f"{label:28s} " + "  ".join(f"{c[3:]} {(d.get(c, 0) - prev.get(c, 0)) / 1e6:7.2f}M" for c in cols))
     prev = d
-print(f"{'whole kernel':28s} " + "  ".join(f"{c[3:]} {prev.get(c, 0) / 1e6:7.2f}M" for c in cols))
+    if x == 0:
+        whole = d
+print(f"{'whole kernel (exit 0)':28s} " + "  ".join(f"{c[3:]} {whole.get(c, 0) / 1e6:7.2f}M" for c in cols))
