@@ -137,9 +137,10 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         // MFMAs are 512 cycles; 200 other instructions are twice that), so everything per k-step is pared down: slots at
         // a fixed pitch of one or two copy instructions per tile (the lanes beyond the slab's end fetch its last piece
         // again and land in the slot's padding; no lane is ever switched off), the copy's source as a scalar base plus
-        // a 32-bit lane offset, operand addresses that differ between the tiles by an immediate.  The rows of a short
-        // last slab beyond obs_dim keep what an earlier copy left in the slot -- observation values, finite -- and meet
-        // zero weights (the packed first layer is zero beyond obs_dim).
+        // a 32-bit lane offset, operand addresses that differ between the tiles by an immediate.  In a short last slab
+        // the lanes beyond its end copy its last 16-byte piece once more into the slot's padding, so the rows beyond
+        // obs_dim hold observation values -- finite, from this or an earlier copy -- and meet zero weights (the packed
+        // first layer is zero beyond obs_dim).
         static_assert(NG % 2 == 0 && HT >= 4, "the fragment parity must carry over a k-step; eight chunks over HT MFMA pairs");
         constexpr int PFD = 3, TILEB = PS == 4 ? 2048 : 1024, SLOTB = 2 * TILEB;
         const int slab_bytes = 64 * n_a;                                // a full slab: 16 rows of n_a floats
@@ -164,7 +165,7 @@ void k_policy_mlp(int n_a, int D, int K1, int A, int TPE, int ntiles, int half_f
         // this lane's 8 operand addresses in tile 0 of slot 0 (tile 1: + TILEB, slot n: + n SLOTB)
         unsigned vrow[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vrow[j] = a_slab + (unsigned)(((8 * h + j) * n_a + r) * 4);
+        for (int j = 0; j < 8; ++j) vrow[j] = a_slab + (unsigned)(((8 * h + j) * n_a + (r < n_a ? r : 0)) * 4);   // (lanes beyond the agents read column 0: inside the tile; their MFMA columns are dead)
         typedef __attribute__((address_space(3))) const float lds_cf;
         auto read_tile = [&](unsigned slot_off, int u, float (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll

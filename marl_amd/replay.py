@@ -257,5 +257,5 @@ class DeviceReplay:
         _lib.check(rc, "asm_replay_gather_f32")
         return obs, act, rew, nxt, done, pri
 
-    def sample(self, N: int, is_prior: bool = True):
-        return self.gather(self.draw_indices(N), is_prior)
+    def sample(self, N: int, is_prior: bool = True, without_replacement: bool = False):
+        return self.gather(self.draw_indices(N, without_replacement=without_replacement), is_prior)
