@@ -145,7 +145,7 @@ bool uses_swarm_kernel(const DevParams &P)
 {
     static const bool off = std::getenv("MARL_AMD_NO_SWARM_KERNEL") != nullptr;          // measurement knob: the generic instantiation
     return P.lat == 2 && P.bins && P.parts <= 1 && !P.periodic && P.EPB == 1 && P.cartesian && P.W <= 32 && P.n_obs >= 2 &&
-           (P.n_obs & 1) == 0 && !off;
+           (P.n_obs & 1) == 0 && P.MW >= 12 && !off;     // (MW: neighbour lists and nearest cells pass through the word keys' area, 24 bytes per agent)
 }
 
 template <typename S>

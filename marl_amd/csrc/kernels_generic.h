@@ -91,6 +91,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
 #pragma unroll
     for (int q = 0; q < 6; ++q) { s6[q] = __builtin_inf(); j6[q] = -1; }
     double nn_min = __builtin_inf();
+    [[maybe_unused]] int perm_a = 0;                                     // large swarm: the agent at this lane's place in the cell list
     if (active) {
         // sorted insert; j arrives in ascending order, so an equal distance already listed stays in front (ties keep
         // the lower index), and once the new entry is placed everything behind it moves down one place
@@ -102,6 +103,9 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         };
         if (swarm) {
             if constexpr (F32) {
+                // (a function of the agent: the large swarm's kernel runs it for the agent at the lane's place in the cell
+                // list, not for the lane's own agent -- see below)
+                auto knn_swarm = [&](const int i, const double px, const double py, int (&j6)[6], double &nn_min) {
                 const float pxf = L.px[i], pyf = L.py[i];
                 // Candidates (fp32 screen) go through a min/max insertion chain on single-precision keys (s32 with
                 // the low 10 bits replaced by the index) that keeps the 8 smallest.  The list is read off the keys
@@ -252,6 +256,26 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                             if (su != 0 && su < nn_min) nn_min = su;
                         }
                 }
+                };
+                if constexpr (SW) {
+                    // Lanes in cell-list order: a wave walks as many candidates as its busiest lane, and agents that sit
+                    // in one bin have the same candidates, while 64 agents with consecutive indices are anywhere (dense
+                    // cluster next to open space).  Lane `row` therefore searches for the agent at place `row` of the
+                    // list and leaves the result -- six indices + 1 as 16-bit halves, the nearest neighbour's squared
+                    // distance -- in LDS (the area of the cell pass's word keys, which the lattice path does not use)
+                    // for the agent's own lane, which reads it behind the next barrier.
+                    const int a = (int)BV->idx[row];
+                    perm_a = a;
+                    int ja[6]; double nna = __builtin_inf();
+                    knn_swarm(a, (double)L.px[a], (double)L.py[a], ja, nna);
+                    unsigned *kj = reinterpret_cast<unsigned *>(L.wkey);
+                    kj[a * 3 + 0] = (unsigned)(ja[0] + 1) | ((unsigned)(ja[1] + 1) << 16);
+                    kj[a * 3 + 1] = (unsigned)(ja[2] + 1) | ((unsigned)(ja[3] + 1) << 16);
+                    kj[a * 3 + 2] = (unsigned)(ja[4] + 1) | ((unsigned)(ja[5] + 1) << 16);
+                    const unsigned long long nb = (unsigned long long)__double_as_longlong(nna);
+                    kj[3 * P.SL + 2 * a] = (unsigned)nb; kj[3 * P.SL + 2 * a + 1] = (unsigned)(nb >> 32);
+                } else
+                    knn_swarm(i, px, py, j6, nn_min);
             }
         } else if (F32 && !periodic) {
             const float pxf = (float)L.px[i], pyf = (float)L.py[i];
@@ -276,7 +300,9 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 if (j != i && s < P.T_sen) consider(j, s);
             }
         }
-        // agent block, column-major flatten of rows [pos_x,pos_y,vel_x,vel_y] (CPP:108-131)
+    }
+    // agent block, column-major flatten of rows [pos_x,pos_y,vel_x,vel_y] (CPP:108-131)
+    auto agent_block = [&]() {
         int r0 = 0;
         if (P.con_self) {
             ocol[0] = (S)px; ocol[(size_t)n_a] = (S)py; ocol[(size_t)2 * n_a] = (S)vx; ocol[(size_t)3 * n_a] = (S)vy;
@@ -299,7 +325,8 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             size_t r = (size_t)(r0 + 4 * q) * n_a;
             ocol[r] = (S)rx; ocol[r + n_a] = (S)ry; ocol[r + 2 * (size_t)n_a] = (S)wx; ocol[r + 3 * (size_t)n_a] = (S)wy;
         }
-    }
+    };
+    if constexpr (!SW) { if (active) agent_block(); }
 
     STAMP(4);
     EXIT_AT(3);
@@ -307,6 +334,23 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     for (int w = row; w < 2 * P.W; w += nthr) L.occ[w] = 0;             // occ and cov are adjacent
     __syncthreads();
     double smin = 0.0; int imin = 0;
+    if constexpr (SW) {
+        if (active) {                                                    // the neighbour list some other lane found for this agent
+            const unsigned *kj = reinterpret_cast<const unsigned *>(L.wkey);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned v = kj[i * 3 + q];
+                j6[2 * q] = (int)(v & 0xFFFFu) - 1; j6[2 * q + 1] = (int)(v >> 16) - 1;
+            }
+            nn_min = __longlong_as_double((long long)((unsigned long long)kj[3 * P.SL + 2 * i] | ((unsigned long long)kj[3 * P.SL + 2 * i + 1] << 32)));
+            agent_block();
+            // the cell pass in the same order (agents of one bin reach the same lattice rows); the nearest cell goes
+            // back to the agent's lane through LDS like the neighbour list
+            const int a = perm_a;
+            const int im = lat_cell_pass_lane(P, *LV, true, L.px[a], L.py[a], L.gx, L.gy, L.mask + (size_t)a * P.MW, L.occ, L.cov);
+            const_cast<unsigned *>(kj)[5 * P.SL + a] = (unsigned)im;
+        }
+    } else
     if (active) {
         bool done = false;
         if constexpr (F32) {
@@ -331,10 +375,16 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     }
     STAMP(5);
     EXIT_AT(4);
-    const double dmin = sqrt(smin);
-    const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
     if constexpr (SW) { if (row == 0) L.cnt[1] = 0; }                    // length of the emission's queue of lists to reduce
     __syncthreads();
+    if constexpr (SW) {
+        if (active) {
+            imin = (int)reinterpret_cast<const unsigned *>(L.wkey)[5 * P.SL + i];
+            const double rx = (double)L.gx[imin] - px, ry = (double)L.gy[imin] - py; smin = rx * rx + ry * ry;
+        }
+    }
+    const double dmin = sqrt(smin);
+    const bool in_flag = dmin < sqrt(2.0) * l_cell / 2;                  // CPP:894
 
     unsigned *mym = L.mask + (size_t)row * P.MW;
     int n_before = 0, n_after = 0, n_occ = 0;

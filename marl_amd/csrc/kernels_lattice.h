@@ -203,9 +203,13 @@ __device__ __forceinline__ int lat_cell_pass_lane(const DevParams &P, const LatV
     for (int w = 0; w < P.W; ++w) mrow[w] = 0;
     const LatLane A = lat_lane_of(P, V, active, px, py);
     unsigned und = 0;                                               // 2 bits per row, 15 rows
+    // A row that exists in the table for no lane of the wave is skipped (lanes that are neighbours in space -- the large
+    // swarm's kernel deals them out that way -- reach the same rows, and most waves of a scattered swarm reach none).
+    const int k_lo = A.inr ? (-A.vb > -7 ? -A.vb : -7) : 8, k_hi = A.inr ? (V.rows - 1 - A.vb < 7 ? V.rows - 1 - A.vb : 7) : -8;
 #pragma unroll 1
     for (int t = 0; t < 15; ++t) {
         const int k = t - 7;
+        if (__ballot(k >= k_lo && k <= k_hi) == 0) continue;
         und |= (lat_row(P, A, V.tab, k, k >= -P.lat_KO && k <= P.lat_KO, V.cols, V.rows, mrow, occ, cov) & 3u) << (2 * t);
     }
     while (und) {                                                   // rare: a run end within rounding distance of its circle
