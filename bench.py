@@ -50,9 +50,12 @@ def f_alg_per_agent_step(n_a: int, n_g_mean: float) -> float:
 
 
 def _profile_for(suffix: str, E: int, n_a: int, S: int):
-    """The newest committed profile summary profiles/rNN_*<suffix> taken on this workload, or None."""
+    """The committed profile summary profiles/rNN_*<suffix> of the newest round taken on this workload, or None (older
+    rounds' files describe older kernels)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_*" + suffix)), reverse=True):
+    paths = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_*" + suffix)), reverse=True)
+    newest = os.path.basename(paths[0])[:3] if paths else ""
+    for path in (q for q in paths if os.path.basename(q).startswith(newest)):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -165,8 +168,10 @@ def main():
                          "window (default: at least 5, and enough for 400 timed steps in total)")
     ap.add_argument("--streams", type=int, default=0,
                     help="shards of the rank's environments, each stepped on its own HIP stream (launches in flight); "
-                         "default: 2, and 4 for swarms of 256 agents or more (one workgroup per environment and CU: the "
-                         "ends of four launches overlap better than those of two)")
+                         "default: 3, and 4 for swarms of 256 agents or more (one workgroup per environment and CU); a "
+                         "stream's next launch waits for the last workgroup of its previous one, and with three or four "
+                         "launches in flight those ends overlap better than with two (a process has four hardware queues: "
+                         "more streams than that share queues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-indices", nargs="?", const="both", default=None, choices=["both", "sensed"],
                     help="also materialise the sensed/occupied index lists (both) or the sensed list only")
@@ -209,10 +214,10 @@ def main():
 
     mark("process group ready")
     if args.streams <= 0:
-        args.streams = 4 if args.agents >= 256 else 2
+        args.streams = 4 if args.agents >= 256 else 3
     E, n_a, K, W, S = args.envs_per_gpu, args.agents, args.steps, args.warmup, args.streams
     # The rank's environments as S shards on S HIP streams (contiguous global ids: the same environments
-    # as one batch of E); S launches are in flight, one shard's ramp and tail under the other's steady state.
+    # as one batch of E); S launches are in flight, one shard's ramp and tail under the others' steady state.
     shards = StreamShards(E, n_a, parts=S, device=device, seed=226, env_id_offset=shard_range(rank, world, E)[0],
                           keep_indices={None: False, "both": True, "sensed": "sensed"}[args.keep_indices], is_boundary=not args.periodic)
 
@@ -231,7 +236,8 @@ def main():
 
     shards.on_each(lambda k, env: reset_one(k, env, 0))
     C = args.graph_steps if args.graph_steps > 0 and EPISODE_LENGTH % args.graph_steps == 0 else 0
-    ring = min(max(K, 1), 64) if C == 0 else next(r for r in range(min(C, 64), 0, -1) if C % r == 0)
+    # 64 precomputed action tensors per shard, used in turn (whatever --steps says: a shorter cycle is a tamer workload)
+    ring = 64 if C == 0 else next(r for r in range(min(C, 64), 0, -1) if C % r == 0)
 
     def draw_actions(k, env):
         a = torch.empty(ring, env.E, 2, n_a, dtype=torch.float32, device=device)
@@ -310,18 +316,22 @@ def main():
     G = 1 if K >= EPISODE_LENGTH else -(-EPISODE_LENGTH // max(K, 1))
     R = args.repeats if args.repeats > 0 else G * max(5, -(-400 // max(G * K, 1)))
     G = min(G, R)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(R + 1)] for _ in range(S)]
+    # (An event record costs its stream a few microseconds between two launches, so the events sit at the block boundaries:
+    # after every window when a window spans an episode, after every G windows otherwise; a block's windows share its time.)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(R // G + 1)] for _ in range(S)]
     t0 = time.perf_counter()
     for k in range(S):
         evs[k][0].record(shards.streams[k])
-    for r in range(R):
+    for r in range(R // G * G):
         run_steps(K, pre + W + r * K)
-        for k in range(S):
-            evs[k][r + 1].record(shards.streams[k])
+        if (r + 1) % G == 0:
+            for k in range(S):
+                evs[k][(r + 1) // G].record(shards.streams[k])
     barrier()
     mark("timed region done")
     wall_all = time.perf_counter() - t0
-    win_seq = [max(evs[k][r].elapsed_time(evs[k][r + 1]) for k in range(S)) for r in range(R)]
+    R = R // G * G
+    win_seq = [max(evs[k][r // G].elapsed_time(evs[k][r // G + 1]) for k in range(S)) / G for r in range(R)]
     if os.environ.get("MARL_AMD_BENCH_WINDOWS") == "1" and rank == 0:
         print("windows ms:", " ".join(f"{w:.3f}" for w in win_seq), file=sys.stderr)
     win_ms = sorted(win_seq)
@@ -329,7 +339,7 @@ def main():
     nb = len(blocks)
     med_ms = blocks[nb // 2] if nb % 2 else 0.5 * (blocks[nb // 2 - 1] + blocks[nb // 2])
     # per stream: launches back to back -> the launch period of the step kernel on that stream, over all windows
-    ev_ms = sum(evs[k][0].elapsed_time(evs[k][R]) for k in range(S)) / S / R
+    ev_ms = sum(evs[k][0].elapsed_time(evs[k][R // G]) for k in range(S)) / S / R
     tmax = torch.tensor([med_ms * 1e-3, wall_all], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -19,15 +19,15 @@ from marl_amd.batched import BatchedAssemblyEnv  # noqa: E402
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n_a = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-# third argument "2": a second batch of the same size is stepped on another stream all the time (the steady state of
-# the two-shard benchmark); only the first batch's launches stamp
-other = None
-if len(sys.argv) > 3 and sys.argv[3] == "2":
+# third argument N: N - 1 more batches of the same size are stepped on streams of their own all the time (the steady
+# state of the N-shard benchmark); only the first batch's launches stamp
+others = []
+for j in range(1, int(sys.argv[3]) if len(sys.argv) > 3 else 1):
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
-        other = BatchedAssemblyEnv(E, n_a, env_id_offset=E)
-        other.reset()
-        other_act = other.random_actions()
+        o = BatchedAssemblyEnv(E, n_a, env_id_offset=j * E)
+        o.reset()
+        others.append((o, o.random_actions(), side))
 env = BatchedAssemblyEnv(E, n_a)
 lib = env.lib
 env.reset()
@@ -42,9 +42,10 @@ for t in range(10):
     buf.zero_()
     act = env.random_actions()
     torch.cuda.synchronize()
-    if other is not None:
+    if others:
         for _ in range(3):
-            other.step(other_act, side.cuda_stream)
+            for o, o_act, side in others:
+                o.step(o_act, side.cuda_stream)
             env.step(act)
     else:
         env.step(act)

@@ -15,7 +15,7 @@ bench)
   b > $O/bench_default.json 2> $O/bench_default.err
   b --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2>> $O/bench_default.err
   : > $O/bench_variants.jsonl
-  for args in "--regime packed" "--periodic" "--keep-indices sensed" "--keep-indices both" "--envs-per-gpu 8192" "--streams 3" \
+  for args in "--regime packed" "--periodic" "--keep-indices sensed" "--keep-indices both" "--envs-per-gpu 8192" "--streams 2" "--streams 4" \
               "--envs-per-gpu 256 --agents 1024 --streams 1" "--envs-per-gpu 256 --agents 1024 --streams 2" \
               "--envs-per-gpu 256 --agents 1024 --streams 4" "--envs-per-gpu 256 --agents 1024 --steps 20 --warmup 5"; do
     line=$(b --no-cpu-baseline $args 2>> $O/bench_variants.err)
@@ -33,13 +33,13 @@ trace)
   cd $R
   cp $(ls $O/trace_default/*/*kernel_stats.csv | head -1) $O/bench_default_kernel_stats.csv
   cp $(ls $O/trace_c4/*/*kernel_stats.csv | head -1) $O/c4_kernel_stats.csv
-  python3 tools/kernel_stats_summary.py $O/bench_default_kernel_stats.csv 4096 30 2 $O/bench_default_kernel_trace.json
+  python3 tools/kernel_stats_summary.py $O/bench_default_kernel_stats.csv 4096 30 3 $O/bench_default_kernel_trace.json
   python3 tools/kernel_stats_summary.py $O/c4_kernel_stats.csv 256 1024 4 $O/c4_kernel_trace.json
   rm -rf $O/trace_default $O/trace_c4
   echo trace-done ;;
 pmc)
   bash tools/pmc.sh r03p/pmc_default --steps 50
-  python3 tools/pmc_summary.py $O/pmc_default k_step --json $O/pmc.json > $O/pmc_k_step_fast_4096x30.txt
+  python3 tools/pmc_summary.py $O/pmc_default k_step --json $O/pmc.json --streams 3 > $O/pmc_k_step_fast_4096x30.txt
   rm -rf $O/pmc_default
   bash tools/pmc.sh r03p/pmc_c4 --steps 50 --envs-per-gpu 256 --agents 1024 --streams 1
   python3 tools/pmc_summary.py $O/pmc_c4 "k_step<" --json $O/c4_pmc.json --envs 256 --agents 1024 --streams 1 > $O/c4_pmc_k_step_256x1024.txt
@@ -50,7 +50,7 @@ phases)
   python3 tools/phase_table.py $O/phase_valu_raw.txt "P0 load,P1 + P2 dynamics and state write,P3 k-NN + lattice rows + nearest cell,(P4: inside P3 on the lattice path),P5 slot lists,P6 emission,P7 reward + statistics,the k-NN block alone with the sign flipped (this run is the whole kernel without it)" > $O/phase_instruction_counts.txt
   bash tools/phase_c4.sh > $O/c4_phase_raw.txt 2>&1
   python3 tools/phase_table.py $O/c4_phase_raw.txt "load,dynamics + state write,k-NN + agent block,cell pass,list sizes + target block,emission,reward,statistics" > $O/c4_phase_counts.txt
-  timeout -k 10 120 python3 tools/diag_phases.py 2048 30 2 > $O/phase_cycles.txt 2>&1
+  timeout -k 10 120 python3 tools/diag_phases.py 1366 30 3 > $O/phase_cycles.txt 2>&1
   timeout -k 10 120 python3 tools/diag_phases.py 256 1024 > $O/c4_phase_cycles.txt 2>&1
   echo phases-done ;;
 esac
