@@ -32,7 +32,19 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+# the attributes step() hands to the kernel: re-pointing one of them (DeviceReplay and StreamShards do that with the
+# outputs) drops the cached argument list
+_STEP_INPUTS = frozenset(("obs", "reward", "a_prior", "p", "dp", "grid_center", "n_g", "l_cell", "neighbor_index", "in_flags",
+                          "nearest_cell", "sensed_index", "occupied_index", "stats", "shape_id", "xform", "training_method",
+                          "_lattice", "params", "E"))
+
+
 class BatchedAssemblyEnv:
+    def __setattr__(self, name, value):
+        if name in _STEP_INPUTS:
+            object.__setattr__(self, "_step_args", None)
+        object.__setattr__(self, name, value)
+
     def __init__(self, num_envs: int, n_a: int = 30, *, device="cuda", seed: int = 226, env_id_offset: int = 0,
                  is_boundary: bool = True, is_con_self_state: bool = True, training_method: str = "llm_rl",
                  shapes=None, r_avoid: Optional[float] = None, d_sen: float = 0.4, n_g_max: Optional[int] = None,
@@ -100,7 +112,7 @@ class BatchedAssemblyEnv:
         self._shape_ng = torch.tensor(self.n_gs, **i32)
         self._shape_lcell = torch.tensor(self.l_cells, dtype=torch.float64, device=dev)
         self._recompute_target = False
-        self._step_sig, self._step_args = None, None
+        self._step_args, self._step_prior, self._lat_ref = None, None, None
         # The shapes' lattice description (include/marl_amd_env.h, asm_lattice): lets the step kernel enumerate lattice
         # rows instead of testing every cell.  It describes grids produced by reset() / set_shape(); it is switched
         # off until the first of those, and by invalidate_lattice() (call it after writing grid_center directly).
@@ -193,35 +205,38 @@ class BatchedAssemblyEnv:
         if a.dtype != torch.float32 or not a.is_contiguous() or a.device != self.p.device or \
                 tuple(a.shape) != (self.E, 2, self.n_a):
             raise ValueError(f"actions must be a contiguous float32 tensor of shape {(self.E, 2, self.n_a)} on {self.device}")
-        prior = self.a_prior if self.training_method == "llm_rl" else None
-        # the argument list only changes when a tensor attribute is re-pointed (DeviceReplay does that with the
-        # outputs); building 17 ctypes pointers per call would otherwise cost more host time than a short launch
-        # takes on the GPU.  Every tensor the kernel touches is part of the signature, so `env.x = other_tensor`
-        # is always honoured.
-        sig = tuple(0 if t is None else t.data_ptr() for t in (
-            self.obs, self.reward, prior, self.p, self.dp, self.grid_center, self.n_g, self.l_cell, self.neighbor_index,
-            self.in_flags, self.nearest_cell, self.sensed_index, self.occupied_index, self.stats, self.shape_id, self.xform))
-        if self._step_sig != sig:
-            self._step_sig = sig
-            self._step_args = [C.byref(self.params), self.E, _ptr(self.p), _ptr(self.dp), None, _ptr(self.grid_center),
-                               _ptr(self.n_g), _ptr(self.l_cell), _ptr(self.neighbor_index), _ptr(self.in_flags),
-                               _ptr(self.nearest_cell), _ptr(self.obs), _ptr(self.reward), _ptr(prior),
-                               _ptr(self.sensed_index), _ptr(self.occupied_index), _ptr(self.stats), 0, None, None]
+        # The argument list only changes when one of the attributes it is built from is assigned (__setattr__ drops it;
+        # DeviceReplay and StreamShards re-point the outputs that way), so `env.x = other_tensor` is always honoured;
+        # building 17 ctypes pointers per call, or even reading 16 data pointers to see whether anything moved, costs more
+        # host time than the rest of the call, and three or four shards per step make the host the limit (10.8 us per
+        # call before, against a 31 us step).  Pointers go in as plain integers (the prototypes are void *).
+        args = self._step_args
+        if args is None:
+            prior = self.a_prior if self.training_method == "llm_rl" else None
+            dp_ = lambda t: None if t is None else t.data_ptr()
+            args = [C.byref(self.params), self.E, dp_(self.p), dp_(self.dp), None, dp_(self.grid_center),
+                    dp_(self.n_g), dp_(self.l_cell), dp_(self.neighbor_index), dp_(self.in_flags),
+                    dp_(self.nearest_cell), dp_(self.obs), dp_(self.reward), dp_(prior),
+                    dp_(self.sensed_index), dp_(self.occupied_index), dp_(self.stats), 0, None, None]
             if self._lattice is not None:
                 self._lattice.shape_id, self._lattice.xform = self.shape_id.data_ptr(), self.xform.data_ptr()
-        args = self._step_args
-        args[4] = C.c_void_p(a.data_ptr()); args[17] = int(self._recompute_target)
-        args[18] = self._lat()
-        args[19] = self._stream() if stream_ptr is None else C.c_void_p(stream_ptr)
+            d = self.__dict__
+            d["_step_args"], d["_step_prior"] = args, prior
+            d["_lat_ref"] = None if self._lattice is None else C.byref(self._lattice)
+        d = self.__dict__
+        args[4] = a.data_ptr(); args[17] = 1 if d["_recompute_target"] else 0
+        args[18] = d["_lat_ref"] if d["lattice_valid"] else None
+        args[19] = torch.cuda.current_stream(self.device).cuda_stream if stream_ptr is None else stream_ptr
         if torch.cuda.current_device() == self._dev_index:
             rc = self.lib.asm_batch_step_f32(*args)
         else:
             with torch.cuda.device(self.device):
                 rc = self.lib.asm_batch_step_f32(*args)
-        _lib.check(rc, "asm_batch_step_f32")
-        self._recompute_target = False
-        self.step_count += 1
-        return self.obs, self.reward, self.done, None, prior
+        if rc:
+            _lib.check(rc, "asm_batch_step_f32")
+        d["_recompute_target"] = False
+        d["step_count"] += 1
+        return self.obs, self.reward, self.done, None, d["_step_prior"]
 
     def random_actions(self, out: Optional[torch.Tensor] = None, step: Optional[int] = None) -> torch.Tensor:
         """U(-1,1) actions from the counter-based generator (assembly.py:519)."""
