@@ -11,8 +11,9 @@ by global id, no data-path collective; one RCCL all-reduce of the 8-value
 episode-statistics vector per 200-step episode.
 
 Timing: R windows of exactly --steps steps each, back to back, bracketed by barrier +
-synchronize; window boundaries are HIP events on the shard streams and the step time
-is the median window / --steps (max over ranks).
+synchronize; HIP events on the shard streams at the boundaries of blocks of windows (one
+window when it spans an episode, else as many as span one) and the step time is the
+median block / its steps (max over ranks).
 
 Rank 0 prints ONE JSON line: whole-job agent-steps/s, the roofline of the dominant
 kernel (k_step) derived from that value, and at N = 1 the CPU baseline (the compiled
@@ -385,8 +386,9 @@ def main():
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "timing": {"clock": "HIP events on the shard streams at the window boundaries; windows shorter than an episode "
-                                "are averaged in blocks that span one; value = agent-steps of one window / median block, "
+            "timing": {"clock": "HIP events on the shard streams at the boundaries of blocks of windows: one window when it "
+                                "spans an episode, else as many as span one (an event after every short window costs the "
+                                "streams 2 %); value = agent-steps of one window / (median block / windows per block), "
                                 "max over ranks",
                        "windows": R, "steps_per_window": K, "windows_per_block": G,
                        "window_ms_min_median_max": [win_ms[0], med_ms, win_ms[-1]],
