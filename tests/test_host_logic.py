@@ -160,7 +160,7 @@ def test_bench_roofline_inputs():
     t = bench.measured_traffic(4096, 30, 3)                  # (bytes per launch: the counters belong to one shard size)
     assert t is not None and t["source"] == "profiles/r03_pmc.json"
     assert t["hbm_bytes_per_launch"] > 0.9 * 1365 * 30 * bench.b_alg_per_agent_step(30, 511.8)
-    assert bench.measured_traffic(4096, 30, 2) is None       # (last round's two-shard passes describe last round's kernel)
+    assert bench.measured_traffic(4096, 30, 2) is None       # (the two-shard passes on file are an older kernel's: not quoted)
     assert bench.measured_traffic(4096, 31, 3) is None
     assert bench.measured_traffic(256, 1024, 1)["source"] == "profiles/r03_c4_pmc.json"
     assert bench.measured_traffic(256, 1024, 4)["source"] == "profiles/r03_c4_pmc.json"      # counter passes serialise the launches
