@@ -359,8 +359,10 @@ def main():
         # (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B).  30 agents: 10.4 FLOP/B -> HBM; 1024 agents: 34.7 -> fp32 VALU.
         valu_bound = f_alg / b_alg > VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
         env0 = shards.envs[0]
+        # (observation rows are stored non-temporal on the lattice path unless the schedule setting's bit 7 says otherwise)
+        nt_off = (int(os.environ.get("MARL_AMD_FAST_T", "4") or 4) & 128) != 0
         kname = step_kernel_name(env0.step_schedule(), args.periodic, {None: 0, "sensed": 1, "both": 2}[args.keep_indices],
-                                 E // S * env0.obs_dim_agent * n_a * 4 > (64 << 20))
+                                 bool(env0.step_schedule() & 16) and not nt_off)
         # committed counters / traces are quoted only for the kernel they were taken on (a periodic arena, index lists or a
         # measurement knob run another instantiation) and for the reference's reset
         same = lambda t: t is not None and args.regime == "random" and any(

@@ -139,9 +139,10 @@ int asm_abi_version(void);
  * MARL_AMD_FAST_T environment variable, read once per process, else 4).  + 16: large swarms (256 agents and more) run
  * their pair passes (contacts, nearest neighbours) over all agents instead of through cell lists.  + 32: large swarms
  * of 512 agents and more on the lattice path step in three launches (dynamics; observation split over 256-agent
- * workgroups; statistics) instead of one.  + 64 / + 128: the multi-wave kernel stores observation rows non-temporal always / never (default:
- * when one launch writes more than 64 MiB of observations, which then would not stay in the last-level cache for their
- * reader anyway and must not evict the grids and the state).  All produce the same results. */
+ * workgroups; statistics) instead of one.  + 128: the multi-wave kernel stores observation rows the ordinary way
+ * instead of non-temporal (the default on its lattice path: rows stored the ordinary way push the grids and the state
+ * out of the last-level cache between two steps; a reader that wants the rows cached sets this bit); + 64 is accepted
+ * and means the default.  All produce the same results. */
 void asm_set_step_schedule(int waves);
 const char *asm_last_error(void);
 /* Number of visible HIP devices, or a negative HIP error code. */

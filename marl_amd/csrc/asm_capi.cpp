@@ -70,18 +70,16 @@ int schedule_setting()
     return o >= 0 ? o : v;
 }
 int fast_t_setting() { return schedule_setting() & 15; }
-// Observation rows are stored non-temporal when one launch writes more than 64 MiB of them: such a batch cannot stay in
-// the last-level cache until the next kernel reads it, and stored the ordinary way it pushes the grids and the state
-// out (16384 environments of 30 agents per GPU: 165 against 139 us per step); a smaller batch is better left in the cache
-// for its reader (4096 environments: the policy kernel behind the step runs 3.5 % faster).  Bit 6 of the schedule
-// setting (+64) forces them on, bit 7 (+128) off.  (The multi-wave kernel only; the large-swarm kernel always stores
-// its cell block non-temporal.)
+// Observation rows are stored non-temporal by the multi-wave kernel's lattice path: stored the ordinary way they push the
+// grids and the state out of the last-level cache between two steps (4096 environments of 30 agents in three shards:
+// 31.5 against 30.8 us per step; 8192: 63.1 against 59.6; 16384 in one launch: 165 against 139).  A consumer that reads
+// them straight back gains little from the cache (the float32 rollout's transpose kernel: no difference; the bf16 policy
+// kernel 1 % faster with cached rows).  Bit 7 of the schedule setting (+128) stores them the ordinary way, bit 6 (+64) is
+// accepted for compatibility (it was "force on").  (The large-swarm kernel always stores its cell block non-temporal.)
 int obs_nt_for(const DevParams &P)
 {
-    const int s = schedule_setting();
-    if (s & 64) return 1;
-    if (s & 128) return 0;
-    return (size_t)P.E * P.obs_dim * P.n_a * 4 > ((size_t)64 << 20) ? 1 : 0;
+    (void)P;
+    return (schedule_setting() & 128) ? 0 : 1;
 }
 bool cell_lists_off() { return (schedule_setting() & 16) != 0; }
 bool split_on() { return (schedule_setting() & 32) != 0; }
