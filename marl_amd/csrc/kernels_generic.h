@@ -75,6 +75,9 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     const double px = active ? (double)L.px[i] : 0.0, py = active ? (double)L.py[i] : 0.0;
     const double vx = active ? (double)L.vx[i] : 0.0, vy = active ? (double)L.vy[i] : 0.0;
     S *ocol = obs_g + (size_t)e * P.obs_dim * n_a + i;                   // obs[row*n_a + agent]
+    // (the large swarm stores every observation row non-temporal: written once, read by a later kernel, and 786 KB per
+    // environment that would otherwise pass through the cache the grids and the state live in)
+    auto oput = [&](size_t r, S v) { if constexpr (SW) __builtin_nontemporal_store(v, ocol + r); else ocol[r] = v; };
     // cell list of the agents for the neighbour search (in the mask area, which the cell pass takes over afterwards)
     [[maybe_unused]] BinView BVs;
     [[maybe_unused]] const BinView *BV = nullptr;
@@ -305,7 +308,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
     auto agent_block = [&]() {
         int r0 = 0;
         if (P.con_self) {
-            ocol[0] = (S)px; ocol[(size_t)n_a] = (S)py; ocol[(size_t)2 * n_a] = (S)vx; ocol[(size_t)3 * n_a] = (S)vy;
+            oput(0, (S)px); oput((size_t)n_a, (S)py); oput((size_t)2 * n_a, (S)vx); oput((size_t)3 * n_a, (S)vy);
             r0 = 4;
         }
 #pragma unroll
@@ -323,7 +326,7 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             }
             nbr_g[((size_t)e * n_a + i) * 6 + q] = j;                    // CPP:103-105
             size_t r = (size_t)(r0 + 4 * q) * n_a;
-            ocol[r] = (S)rx; ocol[r + n_a] = (S)ry; ocol[r + 2 * (size_t)n_a] = (S)wx; ocol[r + 3 * (size_t)n_a] = (S)wy;
+            oput(r, (S)rx); oput(r + n_a, (S)ry); oput(r + 2 * (size_t)n_a, (S)wx); oput(r + 3 * (size_t)n_a, (S)wy);
         }
     };
     if constexpr (!SW) { if (active) agent_block(); }
@@ -406,8 +409,8 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
         if (in_flag) { t0 = px - px; t1 = py - py; t2 = vx - vx; t3 = vy - vy; }
         else { t0 = (double)L.gx[imin] - px; t1 = (double)L.gy[imin] - py; t2 = 0.0 - vx; t3 = 0.0 - vy; }
         const int tb = cartesian ? P.obs_dim - (2 + P.n_obs) * 2 : P.obs_dim - 6;   // CPP:304, 317
-        ocol[(size_t)(tb + 0) * n_a] = (S)t0; ocol[(size_t)(tb + 1) * n_a] = (S)t1;
-        ocol[(size_t)(tb + 2) * n_a] = (S)t2; ocol[(size_t)(tb + 3) * n_a] = (S)t3;
+        oput((size_t)(tb + 0) * n_a, (S)t0); oput((size_t)(tb + 1) * n_a, (S)t1);
+        oput((size_t)(tb + 2) * n_a, (S)t2); oput((size_t)(tb + 3) * n_a, (S)t3);
         if (!cartesian) {                                              // CPP:322-324
             ocol[(size_t)(tb + 4) * n_a] = heading_g[i]; ocol[(size_t)(tb + 5) * n_a] = heading_g[n_a + i];
         }
