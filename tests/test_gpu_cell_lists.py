@@ -136,3 +136,32 @@ def test_split_step_equals_one_workgroup_per_environment(torch_cuda, lists_off, 
     env.invalidate_lattice()                                              # no lattice description: back to the single launch
     assert env.step_schedule() & 128 == 0
     teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), "after invalidate vs oracle")
+
+
+@pytest.mark.parametrize("ctor", [dict(num_obs_grid_max=40), dict(num_obs_grid_max=16, d_sen=0.3), dict(is_con_self_state=False),
+                                  dict(training_method="rl"), dict(keep_stats=False)])
+def test_large_swarm_kernel_other_parameters(torch_cuda, ctor):
+    """The large swarm's own instantiation of the step kernel with other list capacities (most lists sub-sampled, so the
+    reduction of a list to the cells it keeps and the wave-wide reward sums carry the step), without the self-state
+    rows, without the prior, without statistics: against the oracle, from the reference's reset and with every agent
+    packed into its shape (full lists, the occupied-cell filter, rewards)."""
+    torch = torch_cuda
+    from gpu_util import cfg_from_env, teacher_forced_step
+    from marl_amd.batched import BatchedAssemblyEnv
+    E, n_a = 3, 512
+    env = BatchedAssemblyEnv(E, n_a, seed=31, keep_indices=True, **ctor)
+    cfg = cfg_from_env(env)
+    env.reset()
+    assert env.step_schedule() == 32 + 64 + 256
+    rng = np.random.default_rng(3)
+    for t in range(2):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"{ctor} step {t}")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cell = (torch.rand(E, n_a, device="cuda", generator=g) * env.n_g[:, None]).long()
+    pos = torch.gather(env.grid_center, 2, cell[:, None, :].expand(E, 2, n_a))
+    env.p.copy_(pos + 0.03 * torch.randn(E, 2, n_a, device="cuda", generator=g))
+    env.observe()
+    for t in range(3):
+        teacher_forced_step(env, cfg, rng.uniform(-1, 1, (E, 2, n_a)).astype(np.float32), f"{ctor} packed step {t}")
+    if ctor.get("num_obs_grid_max"):
+        assert int((env.sensed_index[:, :, -1] >= 0).sum()) > 0        # lists that fill every slot: sub-sampled or full
