@@ -39,6 +39,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // n_g[e] is caller data in device memory: the kernels read cells [0, min(max(n_g, 0), row length)) whatever it holds
 __device__ __forceinline__ int clamp_ng(int n_g, int n_g_max) { return n_g < 0 ? 0 : (n_g > n_g_max ? n_g_max : n_g); }
 
+// stats[k] += v as one memory-side add without a returned value: the wave does not wait for the old value, so a
+// workgroup ends without a last round trip to memory.  Every statistic has exactly one adding lane per launch (launches
+// of a stream are ordered), so the sum is the same IEEE addition, in the same order, as a load / add / store.
+__device__ __forceinline__ void stat_add(double *p, double v)
+{
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+}
+
 // ---- LDS carve ------------------------------------------------------------------
 template <typename S>
 struct EnvLds {

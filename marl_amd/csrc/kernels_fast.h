@@ -83,13 +83,6 @@ __device__ __forceinline__ double half_max(double v)
     return v;
 }
 
-// stats[k] += v as one memory-side add without a returned value: the wave does not wait for the old value, so a
-// workgroup ends without a last round trip to memory.  Every statistic has exactly one adding lane per launch (launches
-// of a stream are ordered), so the sum is the same IEEE addition, in the same order, as a load / add / store.
-__device__ __forceinline__ void stat_add(double *p, double v)
-{
-    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
-}
 
 // psi(z) of the reward's weighted mean (CPP:1017-1025 with delta = 0), the reference's expression
 __device__ __forceinline__ double reward_weight(const DevParams &P, double z)

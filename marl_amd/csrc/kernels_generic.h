@@ -35,11 +35,11 @@ __device__ __forceinline__ void swarm_stats(const DevParams &P, double *part, in
         const double covered = floor(ic / 65536.0), inn = ic - 65536.0 * covered;    // both are small integers
         const double mean = ms / n_a, var = sq / n_a - mean * mean;
         double *st = stats_g + (size_t)e * 8;
-        st[0] += rs; st[1] += rs;                                        // rewards are 0 or 1
-        if (cov) st[2] += P.n_g_e > 0 ? covered / P.n_g_e : 0.0;
-        st[3] += (var - lo) / (hi - lo);                                 // WRAP:98-99
-        if (contacts >= 0) st[4] += contacts;
-        st[5] += ds / n_a; st[6] += 1.0; st[7] += inn;
+        stat_add(&st[0], rs); stat_add(&st[1], rs);                      // rewards are 0 or 1
+        if (cov) stat_add(&st[2], P.n_g_e > 0 ? covered / P.n_g_e : 0.0);
+        stat_add(&st[3], (var - lo) / (hi - lo));                        // WRAP:98-99
+        if (contacts >= 0) stat_add(&st[4], contacts);
+        stat_add(&st[5], ds / n_a); stat_add(&st[6], 1.0); stat_add(&st[7], inn);
     }
 }
 
