@@ -47,6 +47,42 @@ __device__ __forceinline__ void stat_add(double *p, double v)
     (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
 }
 
+// Requests every 64-byte line of the kernel's argument block at once, as the wave's first instructions, and waits for
+// them.  A launch's arguments lie at a fresh address, so the first waves of a launch on a CU miss the scalar cache on
+// every line; the compiler fetches argument fields where they are first needed, each fetch followed by its own wait, and
+// a kernel with several hundred bytes of arguments then starts with as many round trips to memory in a row as it
+// touches lines.  With all lines in flight together it is one round trip; the compiler's own loads hit the cache.
+// BYTES: the size of the argument block (the explicit arguments; at most 640 bytes are covered).
+// The statement is tied to the workgroup index (returned unchanged) instead of being volatile: a volatile statement counts
+// as a possible write to memory, after which the compiler no longer reads uniform values through the scalar unit.
+template <int BYTES>
+__device__ __forceinline__ int kernarg_warm(int block)
+{
+#ifndef ASM_EXP_NO_KERNARG_WARM
+    static_assert(BYTES >= 4 && BYTES <= 640, "ten lines");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int last = (BYTES - 4) & ~3;
+#define ASM_KA_OFF(k) ((k) * 64 < last ? (k) * 64 : last)
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+    asm("s_load_dword %0, %11, %12\n\t"
+                 "s_load_dword %1, %11, %13\n\t"
+                 "s_load_dword %2, %11, %14\n\t"
+                 "s_load_dword %3, %11, %15\n\t"
+                 "s_load_dword %4, %11, %16\n\t"
+                 "s_load_dword %5, %11, %17\n\t"
+                 "s_load_dword %6, %11, %18\n\t"
+                 "s_load_dword %7, %11, %19\n\t"
+                 "s_load_dword %8, %11, %20\n\t"
+                 "s_load_dword %9, %11, %21\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "+s"(block)
+                 : "s"(ka), "i"(ASM_KA_OFF(0)), "i"(ASM_KA_OFF(1)), "i"(ASM_KA_OFF(2)), "i"(ASM_KA_OFF(3)), "i"(ASM_KA_OFF(4)),
+                   "i"(ASM_KA_OFF(5)), "i"(ASM_KA_OFF(6)), "i"(ASM_KA_OFF(7)), "i"(ASM_KA_OFF(8)), "i"(ASM_KA_OFF(9)));
+#undef ASM_KA_OFF
+#endif
+    return block;
+}
+
 // ---- LDS carve ------------------------------------------------------------------
 template <typename S>
 struct EnvLds {

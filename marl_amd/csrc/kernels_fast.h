@@ -122,11 +122,13 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
     const unsigned long long dg_t0 = __builtin_readcyclecounter();   // the wave's first instruction
     unsigned long long dg_t1 = 0, dg_t2 = 0, dg_b = 0, dg_c = 0;
 #endif
+    // (two structures and 15 pointers, each aligned to 8 bytes: the explicit arguments, which is all this kernel has)
+    const int block = kernarg_warm<((sizeof(DevParams) + 7) & ~7) + ((sizeof(LatArgs) + 7) & ~7) + 15 * 8>((int)blockIdx.x);
     extern __shared__ __align__(16) unsigned char smem[];
     // sub is the same for every lane of a wave: read through the scalar unit so that everything derived from
     // it (word and slot ranges, row offsets) stays in scalar registers
     const int tid = threadIdx.x, sub = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, es = l >> 5, i = l & 31;
-    const int e = blockIdx.x * 2 + es;
+    const int e = block * 2 + es;
     const bool env_ok = e < P.E, active = env_ok && i < P.n_a;
     const int n_a = P.n_a, NGP = P.NGP, W = P.W, MW = P.MW, cap = P.n_obs;
     const FastLds L = carve_fast(smem, P, T, LAT);
@@ -153,7 +155,8 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
     // branch ("environment e0 + 1 exists ? load : 0") gets its own wait inside that branch, and a chain of such waits was
     // six round trips to memory long.  Hence indices clamped to the last environment instead of branches, the values
     // discarded afterwards where the environment does not exist, and the widest loads (the grid rows) first.
-    const int e0 = blockIdx.x * 2;
+    const int e0 = block * 2;
+    __builtin_assume(e0 < P.E);                                     // the grid has (E + 1) / 2 workgroups: loads guarded by it need no branch
     // Per-agent arrays are addressed as a workgroup-uniform base (the first environment of the pair, scalar registers) plus a
     // small per-lane element offset: no 64-bit vector address arithmetic, and nothing 64 bits wide kept per lane for it.
     const int la = es * n_a + i, la2 = es * 2 * n_a + i;            // lane's agent among the pair's agents; its slot in a [2][n_a] array pair
@@ -191,10 +194,15 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
     const double l_cell_r = lcell_g[ec];
     [[maybe_unused]] double xf_c = 1, xf_s = 0, xf_ox = 0, xf_oy = 0;
     if constexpr (LAT) { xf_c = lat.xform[(size_t)ec * 4]; xf_s = lat.xform[(size_t)ec * 4 + 1]; xf_ox = lat.xform[(size_t)ec * 4 + 2]; xf_oy = lat.xform[(size_t)ec * 4 + 3]; }
-    const int ng0r = ng_g[e0c], ng1r = ng_g[e1c];
+    int ng0r = ng_g[e0c], ng1r = ng_g[e1c];
     [[maybe_unused]] int sid0r = 0, sid1r = 0;
     if constexpr (LAT) { sid0r = lat.shape_id[e0c]; sid1r = lat.shape_id[e1c]; }
-    const int ng0 = e0 < P.E ? clamp_ng(ng0r, P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng1r, P.n_g_max) : 0;
+    // (one point at which all four are needed: otherwise each pair is fetched where it is first used, a round trip apart)
+    // (readfirstlane: free for a value the scalar unit loaded; where the compiler took the vector path it moves it over)
+    ng0r = __builtin_amdgcn_readfirstlane(ng0r); ng1r = __builtin_amdgcn_readfirstlane(ng1r);
+    sid0r = __builtin_amdgcn_readfirstlane(sid0r); sid1r = __builtin_amdgcn_readfirstlane(sid1r);
+    asm("" : "+s"(ng0r), "+s"(ng1r), "+s"(sid0r), "+s"(sid1r));
+    const int ng0= e0 < P.E ? clamp_ng(ng0r, P.n_g_max) : 0, ng1 = e0 + 1 < P.E ? clamp_ng(ng1r, P.n_g_max) : 0;
     const int n_g = es ? ng1 : ng0;
 #ifdef ASM_DIAG
     asm volatile("" :: "s"(ng0));
@@ -432,7 +440,11 @@ __global__ __launch_bounds__(64 * T, (LAT && IDX == 0 && !PER) ? ASM_FAST_MINW_L
         __builtin_amdgcn_make_buffer_rsrc(obs_g + (size_t)e0 * P.obs_dim * n_a, 0, 0x7fffffff, 0x00020000);
     const int olb = (es * P.obs_dim * n_a + i) * 4;
     auto ostore = [&](int row, float v) {
+#ifdef ASM_EXP_ALIGNED
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, (row * n_a * 4) & ~127, NT ? 2 : 0);   // timing experiment only: wrong rows
+#else
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), obs_rs, olb, row * n_a * 4, NT ? 2 : 0);
+#endif
     };
     int j6[6];
 #pragma unroll

@@ -482,6 +482,7 @@ def test_captured_steps_equal_eager_steps(torch_cuda):
     b_sh = StreamShards(E, n_a, parts=2, seed=4)
     a_sh.reset(0); b_sh.reset(0)
     acts = a_sh.on_each(lambda k, env: torch.stack([env.random_actions(step=j) for j in range(G)]))
+    a_sh.synchronize()                                                       # b_sh reads them on streams of its own
     a_sh.step([a[0] for a in acts]); b_sh.step([a[0] for a in acts])          # kernels loaded before the capture
     graph = a_sh.capture(lambda: [a_sh.step([a[j] for a in acts]) for j in range(G)])
     assert a_sh.envs[0].step_count == 1                                      # capturing ran nothing
