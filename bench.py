@@ -82,6 +82,20 @@ def profiled_kernel(E: int, n_a: int, S: int):
     return _profile_for("kernel_trace.json", E, n_a, S)
 
 
+def trace_note(kt, S: int, ms_per_step: float):
+    """How the traced run compares with this one: per-dispatch tracing slows the launch pipeline, and a slower pipeline
+    overlaps fewer launches, each of which then runs on a less crowded chip."""
+    traced = kt.get("bench_ms_per_step_under_tracing") if kt else None
+    if not traced:
+        return None
+    inflight = S * kt["avg_us"] * 1e-3 / traced
+    if traced < 1.1 * ms_per_step:
+        return f"the traced run stepped in {traced * 1e3:.1f} us ({inflight:.1f} launches in flight), like this one"
+    return (f"the traced run stepped in {traced * 1e3:.1f} us with {inflight:.1f} launches in flight on average, this run in "
+            f"{ms_per_step * 1e3:.1f} us: kernel_avg_us_profiled is the duration on a less crowded chip, a lower bound of the "
+            f"duration here, and launch_gap_us an upper bound of the gap")
+
+
 def step_kernel_name(code: int, periodic: bool, idx: int, nt: bool) -> str:
     """The kernel asm_batch_step_f32 launches, from asm_debug_step_schedule's code (include/marl_amd_env.h)."""
     T = code & 15
@@ -424,6 +438,9 @@ def main():
                          "kernel_avg_us_profiled": kt["avg_us"] if kt else None,
                          "launch_gap_us": (kern_ms * 1e3 - kt["avg_us"]) if kt else None,
                          "kernel_trace_source": kt["source"] if kt else None,
+                         # (per-dispatch tracing stretches a stream's launch period, so fewer launches overlap under it than
+                         # in this run: the traced duration is that of a less crowded chip)
+                         "kernel_trace_note": trace_note(kt, S, wall / K * 1e3),
                          # HIP events on each shard's stream around all its timed launches, / launches: the launch period
                          # of a stream = kernel duration (rocprofv3 --kernel-trace: profiles/) + dispatch gap
                          "avg_launch_ms": kern_ms,

@@ -33,8 +33,8 @@ trace)
   cd $R
   cp $(ls $O/trace_default/*/*kernel_stats.csv | head -1) $O/bench_default_kernel_stats.csv
   cp $(ls $O/trace_c4/*/*kernel_stats.csv | head -1) $O/c4_kernel_stats.csv
-  python3 tools/kernel_stats_summary.py $O/bench_default_kernel_stats.csv 4096 30 3 $O/bench_default_kernel_trace.json
-  python3 tools/kernel_stats_summary.py $O/c4_kernel_stats.csv 256 1024 4 $O/c4_kernel_trace.json
+  python3 tools/kernel_stats_summary.py $O/bench_default_kernel_stats.csv 4096 30 3 $O/bench_default_kernel_trace.json $O/trace_default.log
+  python3 tools/kernel_stats_summary.py $O/c4_kernel_stats.csv 256 1024 4 $O/c4_kernel_trace.json $O/trace_c4.log
   rm -rf $O/trace_default $O/trace_c4
   echo trace-done ;;
 pmc)
