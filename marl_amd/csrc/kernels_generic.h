@@ -535,7 +535,11 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
             // coordinate reads go out together, then the arithmetic and the eight row stores.  The only branches are uniform
             // across the wave (a lane needs its next word; the wave has no reward term; the lists of all lanes are through).
             constexpr int RB = 4;
+#ifdef ASM_EXP_NOREW
+            const bool any_rew = false;                                  // timing experiment only: rewards are wrong
+#else
             const bool any_rew = __ballot(rew_on) != 0;
+#endif
             auto fetch = [&](unsigned &fb, int &fw) {                    // the lane's next non-empty word (none: no bits)
                 const int w = __ffs(nz) - 1;                             // -1 when none is left
                 nz &= nz - 1;
@@ -594,6 +598,9 @@ __device__ void observe(const DevParams &P, const EnvLds<S> &L, bool active, int
                 const float margin = 1.28f * (float)n_out * __builtin_fmaf(1e-6f, rden, 6e-8f) + 2e-7f;
                 if (__builtin_fabsf(vn - 0.05f) > margin) { uniform = vn < 0.05f; uniform_known = true; }
             }
+#ifdef ASM_EXP_NOREW
+            uniform_known = true;
+#endif
             if (rew_on && n_after > 0 && !uniform_known) exact_by_wave = true;   // borderline: the exact sums, by the wave below
         }
     } else
