@@ -14,7 +14,7 @@ for t in range(20):
 buf = torch.zeros(8192, 32, dtype=torch.int64, device="cuda")
 assert env.lib.asm_diag_set_buffer(C.c_void_p(buf.data_ptr())) == 0
 env.step(env.random_actions()); torch.cuda.synchronize()
-b = buf.cpu().numpy(); b = b[b[:, 9] > 0]
+b = buf.cpu().numpy(); wg = np.nonzero(b[:, 9] > 0)[0]; b = b[b[:, 9] > 0]
 env.lib.asm_diag_set_buffer(None)
 hw = b[:, 20:24]
 simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; wave = hw & 15
@@ -32,3 +32,6 @@ for k in np.unique(key):
     s0 = np.sort(simd[key == k, 0]).tolist()
     dist[tuple(s0)] = dist.get(tuple(s0), 0) + 1
 print("CUs seen:", len(np.unique(key)), "; SIMDs of the first waves of a CU's workgroups -> number of CUs:", sorted(dist.items(), key=lambda kv: -kv[1])[:8])
+# workgroup index -> XCD: round-robin?
+print("workgroups on XCD (workgroup index % 8):", int(((b[:, 24] & 15) == wg % 8).sum()), "of", len(b),
+      "; XCD ids of workgroups 0..15:", (b[:16, 24] & 15).tolist())
