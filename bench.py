@@ -32,6 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+HBM_COPY_GBS = 6290.0          # measured rate of a float4 copy on MI355X (79 % of the peak)
 VALU_PEAK_TFLOPS = 157.3       # MI355X fp32 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x 2.4 GHz)
 EPISODE_LENGTH = 200           # marl_llm/cfg/assembly_cfg.py:192
 SETTLE_STEPS = int(os.environ.get("MARL_AMD_BENCH_SETTLE", "1200"))   # untimed steps of continuous load before the step time is steady
@@ -61,7 +62,7 @@ def _profile_for(suffix: str, E: int, n_a: int, S: int):
             with open(path) as f:
                 t = json.load(f)
             w = t["workload"]
-            if (w["envs_per_gpu"], w["agents"]) == (E, n_a) and w.get("streams", S) in (S, 1):
+            if (w["envs_per_gpu"], w["agents"]) == (E, n_a):     # (however the run shards them: the files say how they did)
                 t["source"] = "profiles/" + os.path.basename(path)
                 return t
         except (OSError, ValueError, KeyError, TypeError):
@@ -107,16 +108,27 @@ def step_kernel_name(code: int, periodic: bool, idx: int, nt: bool) -> str:
     return name + (f" ({', '.join(extras)})" if extras else "")
 
 
-def limiter_note(tr, valu_bound: bool) -> str:
-    """What the committed counters say limits the kernel (one launch alone on the chip)."""
+def limiter_note(tr, valu_bound: bool, S: int = 1, step_us: float = 0.0) -> str:
+    """What the committed counters say limits the kernel.  Counter passes serialise the launches, so the counters are
+    one launch alone on the chip; the run itself keeps S launches in flight, and a step's vector-issue cycles (active VALU
+    quad-cycles x 4 per SIMD, summed over the launches of a step) against the step's cycles at 2.39 GHz give the issue load
+    of the run."""
     if not tr:
         return "no counter pass committed for this workload"
     vb, wa = tr.get("valu_busy"), tr.get("sq_wait_any_frac_of_wave_cycles")
     if vb is None:
         return "counter summary without VALU busy"
-    head = f"vector issue {vb:.2f} busy" + (f", waves waiting {wa:.2f} of their cycles" if wa is not None else "")
-    if vb >= 0.6:
-        kind = "limited by vector-instruction issue"
+    head = f"one launch alone: vector issue {vb:.2f} busy" + (f", waves waiting {wa:.2f} of their cycles" if wa is not None else "")
+    av = (tr.get("counters") or {}).get("SQ_ACTIVE_INST_VALU")
+    per_step = (tr.get("workload") or {}).get("streams", S)           # launches per step in the counter run (its shards)
+    steady = (per_step * av * 4.0 / 1024.0) / (step_us * 1e-6 * 2.39e9) if av and step_us > 0 else None
+    if steady is not None and S > 1:
+        head += f"; this run, {S} launches in flight: about {steady:.2f} busy"
+    top = max(vb, steady or 0.0)
+    if top >= 0.6:
+        kind = ("limited by instruction issue: with every workgroup slot taken the step time is throughput, and the waves of a SIMD "
+                "(vector, scalar and branch instructions in order, LDS and memory waits, barriers) do not present a vector "
+                "instruction more often") if vb < 0.6 else "limited by vector-instruction issue"
     elif wa is not None and wa >= 0.4:
         kind = "limited by latency: dependent instruction chains and memory round trips of the waves, not issue or bandwidth"
     else:
@@ -383,8 +395,9 @@ def main():
             k.replace("void ", "") == kname.split(" (")[0] for k in (t["kernel"] if isinstance(t["kernel"], list) else [t["kernel"]]))
         tr = measured_traffic(E, n_a, S)
         tr = tr if same(tr) else None
+        pmc_step_bytes = tr["hbm_bytes_per_launch"] * tr["workload"].get("streams", S) if tr else 0.0
         kt = profiled_kernel(E, n_a, S)
-        kt = kt if same(kt) else None
+        kt = kt if same(kt) and kt["workload"].get("streams") == S else None     # (a launch's duration depends on its size)
         if valu_bound:
             achieved, peak, unit = per_gpu * f_alg / 1e12, VALU_PEAK_TFLOPS, "TFLOP/s"
         else:
@@ -421,14 +434,17 @@ def main():
             # achieved = (agent-steps/s of one GPU) x algorithmic bytes (or FLOPs) per agent-step; frac = achieved / peak
             "roofline": {"bound": "valu" if valu_bound else "hbm", "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak,
-                         # PMC bytes per launch x launches in flight / this run's launch period, in GB/s
-                         "traffic": (S * tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9) if tr else None,
+                         # PMC bytes per launch x the counter run's launches per step / this run's step time, in GB/s
+                         "traffic": (pmc_step_bytes / (wall / K) / 1e9) if tr else None,
                          "traffic_bytes_per_launch": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_launches_per_step": tr["workload"].get("streams", S) if tr else None,
+                         # the same traffic against what a plain float4 copy reaches on this chip (6.29 of the 8 TB/s)
+                         "traffic_frac_of_copy_rate": (pmc_step_bytes / (wall / K) / 1e9 / HBM_COPY_GBS) if tr else None,
                          "traffic_source": (tr["source"] + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)") if tr else None,
                          # rocprof's VALUBusy formula on the same PMC passes (counters serialise the launches, so
                          # this is one launch alone on the chip)
                          "valu_busy_one_launch": tr.get("valu_busy") if tr else None,
-                         "limiter": limiter_note(tr, valu_bound),
+                         "limiter": limiter_note(tr, valu_bound, S, wall / K * 1e6),
                          "launches_in_flight": S, "alg_bytes_per_launch": per_launch * b_alg,
                          "alg_flops_per_launch": per_launch * f_alg,
                          "kernel": kname + " (asm_batch_step_f32)",
