@@ -160,7 +160,8 @@ def test_bench_roofline_inputs():
     t = bench.measured_traffic(4096, 30, 3)                  # (bytes per launch: the counters belong to one shard size)
     assert t is not None and t["source"] == "profiles/r03_pmc.json"
     assert t["hbm_bytes_per_launch"] > 0.9 * 1365 * 30 * bench.b_alg_per_agent_step(30, 511.8)
-    assert bench.measured_traffic(4096, 30, 2) is None       # (the two-shard passes on file are an older kernel's: not quoted)
+    # (a run sharded otherwise quotes the same file: bytes per launch x the file's launches per step are a step's bytes)
+    assert bench.measured_traffic(4096, 30, 2)["workload"]["streams"] == 3
     assert bench.measured_traffic(4096, 31, 3) is None
     assert bench.measured_traffic(256, 1024, 1)["source"] == "profiles/r03_c4_pmc.json"
     assert bench.measured_traffic(256, 1024, 4)["source"] == "profiles/r03_c4_pmc.json"      # counter passes serialise the launches
@@ -180,6 +181,13 @@ def test_bench_roofline_inputs():
             assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
             assert r["achieved"] == pytest.approx(per_gpu * r["alg_bytes_per_agent_step"] / 1e9)
         assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+        if r["traffic"] is not None:                          # counters' bytes of a whole step / this line's step time
+            step_bytes = r["traffic_bytes_per_launch"] * r["traffic_launches_per_step"]
+            assert r["traffic"] == pytest.approx(step_bytes / (line["ms_per_step"] * 1e-3) / 1e9)
+            assert 0.9 * c["envs_per_gpu"] * c["agents"] * r["alg_bytes_per_agent_step"] < step_bytes
+            assert r["traffic"] < 8000.0
+        if r["kernel_avg_us_profiled"] is not None:           # quoted only for a run sharded like the traced one
+            assert r["kernel_avg_us_profiled"] < r["avg_launch_ms"] * 1e3 and r["launch_gap_us"] > 0
         assert line["value"] == pytest.approx(c["global_envs"] * c["agents"] / (line["ms_per_step"] * 1e-3))
         assert line["timing"]["windows"] >= 5 and line["timing"]["steps_per_window"] == line["steps"]
         assert f'{c["agents"]}-agent' in line["metric"]
