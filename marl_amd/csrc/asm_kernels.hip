@@ -129,7 +129,8 @@ int launch_step_fast(const DevParams &P, const LatArgs &lat, float *p, float *dp
 {
 #ifdef ASM_EXITS
     { const char *x = std::getenv("MARL_AMD_DBG_EXIT"); const int v = x ? std::atoi(x) : 0;
-      if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
+      static int set_to = -1;                                       // (copied when it changes: a copy per launch would serialise the streams)
+      if (v != set_to) { if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; set_to = v; } }
 #endif
     if (P.periodic)                                                 // the host offers the periodic arena at T = 4 only
         return launch_step_fast_t<4, true>(P, lat, p, dp, act, grid, n_g, l_cell, nbr, inflags, nearest, obs, rew, prior, sensed, occupied, stats, st);
@@ -155,7 +156,8 @@ int launch_step(const DevParams &P, const LatArgs &lat, S *p, S *dp, const float
 {
 #ifdef ASM_EXITS
     { const char *x = std::getenv("MARL_AMD_DBG_EXIT"); const int v = x ? std::atoi(x) : 0;
-      if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; }
+      static int set_to = -1;                                       // (copied when it changes: a copy per launch would serialise the streams)
+      if (v != set_to) { if (hipMemcpyToSymbol(HIP_SYMBOL(g_exit_at), &v, sizeof v) != hipSuccess) return -1; set_to = v; } }
 #endif
     if constexpr (sizeof(S) == 4) {
         // the large swarm's own instantiation: walls, lattice description, cell lists, the whole environment in one workgroup
